@@ -1,0 +1,112 @@
+/* ragroute_hip.h — C ABI of libragroute_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for RAGRoute's retrieval hot path.  The reference (sacs-epfl/ragroute) has
+ * no FFI of its own: its hot path calls `faiss` / `torch.nn` / `numpy` from Python.  Each entry
+ * point below replaces one of those numeric call sites; the reference file:line it stands in for
+ * is cited per function.  All pointers named `d_*` / marked "device" are HIP device pointers;
+ * `stream` is a `hipStream_t` passed as `void*` (NULL = default stream).  No function synchronises
+ * the host with the device; results are valid once the stream has drained.  No function aborts:
+ * every one returns RR_OK (0) or a negative rr_status and records a message for rr_last_error().
+ */
+#ifndef RAGROUTE_HIP_H
+#define RAGROUTE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rr_status {
+  RR_OK = 0,
+  RR_ERR_INVALID = -1,     /* bad argument (shape, k, dtype, null pointer) */
+  RR_ERR_UNSUPPORTED = -2, /* valid request this build has no kernel for */
+  RR_ERR_WORKSPACE = -3,   /* workspace too small */
+  RR_ERR_HIP = -4          /* a HIP runtime call or kernel launch failed */
+} rr_status;
+
+enum { RR_DTYPE_F16 = 0, RR_DTYPE_BF16 = 1 };
+enum { RR_MAX_K = 1024, RR_QUERY_BLOCK = 256 };
+
+/* Library version (major*10000 + minor*100 + patch). */
+int rr_version(void);
+/* Message of the last failure on the calling thread ("" if none). */
+const char* rr_last_error(void);
+/* Number of compute units of the current device (the persistent scan grid), or <0 on error. */
+int rr_device_cus(void);
+
+/* Row width (in elements) the scan kernel needs for embedding dimension d: the corpus and the
+ * queries must be stored with this leading dimension, zero padded.  <0 if d is unsupported. */
+int rr_padded_dim(int d);
+
+/* In-place row-wise L2 normalisation of an f32 matrix, zero-norm rows left unchanged.
+ * Replaces `faiss.normalize_L2(query_vec)` — reference ragroute/data_source.py:198-199
+ * (also mmlu.py:105-106).  x: device f32 [n][d] contiguous. */
+int rr_l2_normalize_f32(float* d_x, int64_t n, int64_t d, void* stream);
+
+/* Ingest: convert f32 rows to the HBM-resident scan format (f16 or bf16, leading dimension
+ * d_out >= d, zero padded), optionally L2-normalising each row first (cosine corpora).
+ * Stands in for what `faiss.read_index` leaves in memory — reference
+ * ragroute/data_source.py:69-80 — and is also used to prepare query batches
+ * (data_source.py:113-114 builds the f32 [1,d] query).
+ * d_x: device f32, n rows of d values, row stride ld_in; d_out: device [n][d_out] halves. */
+int rr_rows_to_half(const float* d_x, int64_t n, int64_t d, int64_t ld_in, void* d_out, int dtype,
+                    int64_t d_out_dim, int normalize, void* stream);
+
+/* Bytes of device workspace rr_flat_search needs for this k on the current device. */
+size_t rr_flat_search_workspace_bytes(int k);
+
+/* Exact brute-force inner-product top-k of nq queries against an HBM-resident corpus.
+ * Replaces `index.search(query_embed, k)` — reference ragroute/data_source.py:158, 186, 203
+ * (med_rag.py:158, mmlu.py:109): returns, per query, the k best rows best-first; ties are
+ * broken by ascending row id; if fewer than k rows exist the tail is (-inf, -1) as FAISS pads.
+ *   d_xb     device [n_rows][dim] f16/bf16, dim == rr_padded_dim(d) (zero padded)
+ *   d_xq     device [nq][dim] same dtype
+ *   d_D      device f32 [nq][k]  scores (inner products, f32 accumulation)
+ *   d_I      device i64 [nq][k]  row ids + id_offset (shard base), or -1
+ *   d_ws     device workspace of at least rr_flat_search_workspace_bytes(k) bytes
+ * Any nq >= 0 is accepted (served in blocks of RR_QUERY_BLOCK); each query's result is the same
+ * as that of a single-query call, as the reference issues them (data_source.py:114). */
+int rr_flat_search(const void* d_xb, int dtype, int64_t n_rows, int dim, const void* d_xq, int nq, int k,
+                   float* d_D, int64_t* d_I, int64_t id_offset, void* d_ws, size_t ws_bytes, void* stream);
+
+/* Cross-source candidate merge: per query, the k best of m (score, id) candidates.
+ * Replaces `np.argsort(scores)[::-1][:k]` / `np.argsort(scores)[:k]` — reference
+ * ragroute/rerank.py:3-9 (rerank_medrag) and :28-34 (rerank_wikipedia) — applied to the
+ * concatenated per-source lists of ragroute/http_server.py:280-293.  descending != 0 keeps the
+ * highest scores; ties by ascending id; entries with id < 0 are padding and sort last.
+ *   d_Din f32 [nq][m], d_Iin i64 [nq][m]  ->  d_Dout f32 [nq][k], d_Iout i64 [nq][k]. m <= 8192. */
+int rr_merge_topk(const float* d_Din, const int64_t* d_Iin, int nq, int m, int k, int descending,
+                  float* d_Dout, int64_t* d_Iout, void* stream);
+
+/* Router MLP (CorpusRoutingNN) with the feature build and StandardScaler folded into fc1.
+ * Replaces, for a batch of queries, reference ragroute/router.py:241-283
+ * (select_relevant_sources_ragroute: pad/concat features, scaler.transform, model forward,
+ * sigmoid, threshold) and router.py:50-55 (CorpusRoutingNN.forward).  All pointers device f32. */
+typedef struct rr_router_weights {
+  int32_t n_sources;               /* C: rows per query */
+  int32_t d_max;                   /* padded query-embedding length (config.py:92-96) */
+  int32_t n_models;                /* distinct query-embedding models M */
+  int32_t reserved;
+  const int32_t* model_of_source;  /* [C] which of the M embeddings source c uses */
+  const float* w1q;                /* [d_max][256] fc1 query block, transposed, scaler folded */
+  const float* c1;                 /* [C][256] per-source constant: b1 + centroid + one-hot + scaler mean terms */
+  const float* ln1_g; const float* ln1_b;   /* [256] */
+  const float* w2;                 /* [256][128] fc2 transposed */
+  const float* b2; const float* ln2_g; const float* ln2_b; /* [128] */
+  const float* w3;                 /* [128] */
+  float b3;
+  float prob_threshold;            /* 0.4924 medrag, 0.5 otherwise (router.py:277-280) */
+  float ln_eps;                    /* 1e-5 */
+  float reserved2;
+} rr_router_weights;
+/*   d_xq     f32 [nq][M][d_max] zero-padded query embeddings (one per model)
+ *   d_logits f32 [nq][C]   fc3 output
+ *   d_mask   u8  [nq][C]   1 where sigmoid(logit) > prob_threshold */
+int rr_router_mlp(const rr_router_weights* w, const float* d_xq, int nq, float* d_logits, uint8_t* d_mask,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAGROUTE_HIP_H */

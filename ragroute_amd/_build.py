@@ -1,0 +1,23 @@
+"""Build libragroute_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build()."""
+import os
+import subprocess
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libragroute_hip.so")
+SOURCES = ["capi.hip", "flat_scan.hip", "select.hip", "prep.hip", "router.hip"]
+
+
+def build(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("rr_common.h", "rr_kernels.h")] + [
+        os.path.join(os.path.dirname(CSRC), "..", "include", "ragroute_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-o", LIB_PATH] + srcs
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout, res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed building libragroute_hip.so:\n" + res.stderr[-4000:])
+    return LIB_PATH

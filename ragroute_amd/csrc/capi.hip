@@ -1,0 +1,195 @@
+// C ABI of libragroute_hip.so (declared in include/ragroute_hip.h) and the host-side schedule of
+// the flat search: bootstrap threshold -> geometrically growing scan chunks, each followed by an
+// exact compaction that publishes the next per-query threshold -> finalize.  Everything is
+// enqueued on the caller's stream; nothing here synchronises with the device.
+#include <stdio.h>
+#include <string.h>
+
+#include "rr_common.h"
+#include "rr_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* detail = "") {
+  snprintf(g_err, sizeof(g_err), fmt, detail);
+  return code;
+}
+int hip_fail(hipError_t e, const char* where) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+  return RR_ERR_HIP;
+}
+
+int device_cus() {
+  static thread_local int cached_dev = -1, cached = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (dev != cached_dev) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    cached = v;
+    cached_dev = dev;
+  }
+  return cached;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Workspace {
+  float* thr;
+  uint32_t* list_cnt;
+  uint64_t* list;
+  uint32_t* cand_cnt;
+  uint64_t* scratch;
+  float* dense;
+  uint64_t* cand;
+  size_t total;
+};
+
+Workspace carve(char* base, int k, int grid) {
+  using namespace rr;
+  const int cap = cand_cap_for_k(k);
+  Workspace w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return base ? base + o : (char*)nullptr; };
+  w.thr = (float*)take(kQueriesPerBlock * sizeof(float));
+  w.list_cnt = (uint32_t*)take(kQueriesPerBlock * sizeof(uint32_t));
+  w.list = (uint64_t*)take((size_t)kQueriesPerBlock * kMaxK * sizeof(uint64_t));
+  w.cand_cnt = (uint32_t*)take((size_t)kQueriesPerBlock * grid * 2 * sizeof(uint32_t));
+  w.scratch = (uint64_t*)take((size_t)grid * 4 * cap * sizeof(uint64_t));
+  w.dense = (float*)take((size_t)kQueriesPerBlock * kSampleRows * sizeof(float));
+  w.cand = (uint64_t*)take((size_t)kQueriesPerBlock * grid * 2 * cap * sizeof(uint64_t));
+  w.total = off;
+  return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rr_version(void) { return 100; }
+const char* rr_last_error(void) { return g_err; }
+int rr_device_cus(void) {
+  int v = device_cus();
+  return v > 0 ? v : fail(RR_ERR_HIP, "rr_device_cus: no HIP device%s");
+}
+int rr_padded_dim(int d) {
+  if (d <= 0) return RR_ERR_INVALID;
+  int p = rr::scan_padded_dim(d);
+  return p > 0 ? p : RR_ERR_UNSUPPORTED;
+}
+
+int rr_l2_normalize_f32(float* x, int64_t n, int64_t d, void* stream) {
+  if (n < 0 || d <= 0 || (!x && n > 0)) return fail(RR_ERR_INVALID, "rr_l2_normalize_f32: bad arguments%s");
+  hipError_t e = rr::launch_l2_normalize_f32(x, n, d, (hipStream_t)stream);
+  return e == hipSuccess ? RR_OK : hip_fail(e, "rr_l2_normalize_f32");
+}
+
+int rr_rows_to_half(const float* x, int64_t n, int64_t d, int64_t ld_in, void* out, int dtype, int64_t d_out,
+                    int normalize, void* stream) {
+  if (n < 0 || d <= 0 || ld_in < d || d_out < d || ((!x || !out) && n > 0))
+    return fail(RR_ERR_INVALID, "rr_rows_to_half: bad arguments%s");
+  if (dtype != RR_DTYPE_F16 && dtype != RR_DTYPE_BF16) return fail(RR_ERR_INVALID, "rr_rows_to_half: bad dtype%s");
+  hipError_t e = rr::launch_rows_to_half(x, n, d, ld_in, out, dtype, d_out, normalize, (hipStream_t)stream);
+  return e == hipSuccess ? RR_OK : hip_fail(e, "rr_rows_to_half");
+}
+
+size_t rr_flat_search_workspace_bytes(int k) {
+  if (k < 1 || k > rr::kMaxK) return 0;
+  int grid = device_cus();
+  if (grid <= 0) return 0;
+  return carve(nullptr, k, grid).total;
+}
+
+int rr_flat_search(const void* xb, int dtype, int64_t n_rows, int dim, const void* xq, int nq, int k, float* D,
+                   int64_t* I, int64_t id_offset, void* ws, size_t ws_bytes, void* stream) {
+  using namespace rr;
+  hipStream_t st = (hipStream_t)stream;
+  if (k < 1 || k > kMaxK) return fail(RR_ERR_INVALID, "rr_flat_search: k must be in [1, 1024]%s");
+  if (nq < 0 || n_rows < 0) return fail(RR_ERR_INVALID, "rr_flat_search: negative size%s");
+  if (n_rows > 0xFFFFFFE0ll) return fail(RR_ERR_UNSUPPORTED, "rr_flat_search: more than 2^32-32 rows per shard%s");
+  if (dtype != RR_DTYPE_F16 && dtype != RR_DTYPE_BF16) return fail(RR_ERR_INVALID, "rr_flat_search: bad dtype%s");
+  if (scan_padded_dim(dim) != dim)
+    return fail(RR_ERR_UNSUPPORTED, "rr_flat_search: dim must equal rr_padded_dim(d) (128..768 in this build)%s");
+  if (nq == 0) return RR_OK;
+  if (!xq || !D || !I || !ws || (!xb && n_rows > 0)) return fail(RR_ERR_INVALID, "rr_flat_search: null pointer%s");
+  const int grid = device_cus();
+  if (grid <= 0) return fail(RR_ERR_HIP, "rr_flat_search: no HIP device%s");
+  Workspace w = carve((char*)ws, k, grid);
+  if (ws_bytes < w.total) return fail(RR_ERR_WORKSPACE, "rr_flat_search: workspace smaller than rr_flat_search_workspace_bytes(k)%s");
+
+  const int cap = cand_cap_for_k(k);
+  const uint32_t total_tiles = (uint32_t)((n_rows + kTileRows - 1) / kTileRows);
+  hipError_t e;
+#define RR_CHECK(call, what) do { e = (call); if (e != hipSuccess) return hip_fail(e, what); } while (0)
+
+  for (int qb = 0; qb < nq; qb += kQueriesPerBlock) {
+    const int nqb = nq - qb < kQueriesPerBlock ? nq - qb : kQueriesPerBlock;
+    const char* xq_b = (const char*)xq + (size_t)qb * dim * 2;
+    float* D_b = D + (size_t)qb * k;
+    int64_t* I_b = I + (size_t)qb * k;
+
+    SelectArgs s;
+    memset(&s, 0, sizeof(s));
+    s.thr = w.thr; s.list = w.list; s.list_cnt = w.list_cnt; s.cand = w.cand; s.cand_cnt = w.cand_cnt;
+    s.dense = w.dense; s.dense_ld = kSampleRows; s.n_rows = (uint32_t)n_rows; s.nq = (uint32_t)nqb;
+    s.nbuf = (uint32_t)grid * 2; s.list_ld = kMaxK; s.cap = cap; s.k = k;
+    ScanArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xb = xb; a.xq = xq_b; a.thr = w.thr; a.cand = w.cand; a.cand_cnt = w.cand_cnt; a.scratch = w.scratch;
+    a.dense = w.dense; a.n_rows = (uint32_t)n_rows; a.nq = (uint32_t)nqb; a.dense_ld = kSampleRows; a.cap = cap; a.k = k;
+
+    RR_CHECK(launch_init_state(s, st), "rr_flat_search/init");
+    if (n_rows > 0 && n_rows <= kDenseMaxRows) {
+      // tiny corpus: all scores, one exact selection
+      a.tile_first = 0; a.tile_stride = 1; a.n_tiles = total_tiles;
+      RR_CHECK(launch_flat_scan(a, dtype, dim, true, grid, st), "rr_flat_search/dense");
+      s.tile_first = 0; s.tile_stride = 1; s.dense_cols = total_tiles * kTileRows;
+      RR_CHECK(launch_dense_select(s, false, st), "rr_flat_search/dense_select");
+    } else if (n_rows > 0) {
+      // bootstrap: k-th best score of a strided sample of tiles = a valid lower bound
+      const uint32_t n_sample_tiles = kSampleRows / kTileRows;
+      a.tile_first = 0; a.tile_stride = total_tiles / n_sample_tiles; a.n_tiles = n_sample_tiles;
+      RR_CHECK(launch_flat_scan(a, dtype, dim, true, grid, st), "rr_flat_search/bootstrap");
+      s.tile_first = 0; s.tile_stride = a.tile_stride; s.dense_cols = kSampleRows;
+      RR_CHECK(launch_dense_select(s, true, st), "rr_flat_search/bootstrap_select");
+      // chunks [0,e1), [e1,e2), ... with e growing 8x: ~7k survivors per query and chunk
+      uint64_t begin = 0, end = (uint64_t)kSampleRows / kTileRows * kChunkGrowth;  // in tiles
+      while (begin < total_tiles) {
+        if (end > total_tiles) end = total_tiles;
+        a.tile_first = (uint32_t)begin; a.tile_stride = 1; a.n_tiles = (uint32_t)(end - begin);
+        RR_CHECK(launch_flat_scan(a, dtype, dim, false, grid, st), "rr_flat_search/scan");
+        RR_CHECK(launch_compact(s, st), "rr_flat_search/compact");
+        begin = end;
+        end *= kChunkGrowth;
+      }
+    }
+    RR_CHECK(launch_finalize(s, D_b, I_b, id_offset, st), "rr_flat_search/finalize");
+  }
+#undef RR_CHECK
+  return RR_OK;
+}
+
+int rr_merge_topk(const float* Din, const int64_t* Iin, int nq, int m, int k, int descending, float* Dout,
+                  int64_t* Iout, void* stream) {
+  if (nq < 0 || m < 0 || k < 1) return fail(RR_ERR_INVALID, "rr_merge_topk: bad sizes%s");
+  if (m > rr::kSelectCap) return fail(RR_ERR_UNSUPPORTED, "rr_merge_topk: m > 8192 candidates per query%s");
+  if (nq == 0) return RR_OK;
+  if ((m > 0 && (!Din || !Iin)) || !Dout || !Iout) return fail(RR_ERR_INVALID, "rr_merge_topk: null pointer%s");
+  hipError_t e = rr::launch_merge_topk(Din, Iin, nq, m, k, descending, Dout, Iout, (hipStream_t)stream);
+  return e == hipSuccess ? RR_OK : hip_fail(e, "rr_merge_topk");
+}
+
+int rr_router_mlp(const rr_router_weights* w, const float* xq, int nq, float* logits, uint8_t* mask, void* stream) {
+  if (!w || nq < 0) return fail(RR_ERR_INVALID, "rr_router_mlp: bad arguments%s");
+  if (w->n_sources < 1 || w->d_max < 1 || w->n_models < 1 || w->d_max > 8192)
+    return fail(RR_ERR_INVALID, "rr_router_mlp: bad weight header%s");
+  if (nq == 0) return RR_OK;
+  if (!xq || !logits || !mask || !w->w1q || !w->c1 || !w->w2 || !w->w3 || !w->model_of_source)
+    return fail(RR_ERR_INVALID, "rr_router_mlp: null pointer%s");
+  hipError_t e = rr::launch_router_mlp(w, xq, nq, logits, mask, (hipStream_t)stream);
+  return e == hipSuccess ? RR_OK : hip_fail(e, "rr_router_mlp");
+}
+
+}  // extern "C"

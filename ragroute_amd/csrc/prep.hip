@@ -1,0 +1,88 @@
+// K0: row-wise L2 normalisation and the f32 -> f16/bf16 ingest conversion.
+//  * l2_normalize_f32 : in-place, zero-norm rows unchanged — `faiss.normalize_L2`, reference
+//                       ragroute/data_source.py:198-199
+//  * rows_to_half     : f32 rows -> HBM scan format (padded leading dimension), optional normalise
+// One wave per row; 16-byte loads; wave-shuffle reduction of the squared norm.
+#include "rr_common.h"
+#include "rr_kernels.h"
+
+namespace rr {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float row_sumsq(const float* x, int64_t d, int lane) {
+  float acc = 0.f;
+  if ((d & 3) == 0 && (((uintptr_t)x) & 15) == 0) {
+    const float4* x4 = (const float4*)x;
+    for (int64_t i = lane; i < d / 4; i += 64) {
+      const float4 v = x4[i];
+      acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+  } else {
+    for (int64_t i = lane; i < d; i += 64) acc += x[i] * x[i];
+  }
+  return wave_sum(acc);
+}
+
+__global__ __launch_bounds__(256) void l2_normalize_f32_kernel(float* x, int64_t n, int64_t d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wpb = blockDim.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); row < n; row += (int64_t)gridDim.x * wpb) {
+    float* xr = x + row * d;
+    const float nr = row_sumsq(xr, d, lane);
+    if (nr > 0.f) {
+      const float inv = 1.0f / sqrtf(nr);
+      for (int64_t i = lane; i < d; i += 64) xr[i] *= inv;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rows_to_half_kernel(const float* x, int64_t n, int64_t d, int64_t ld_in, T* out,
+                                                           int64_t d_out, int normalize) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wpb = blockDim.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); row < n; row += (int64_t)gridDim.x * wpb) {
+    const float* xr = x + row * ld_in;
+    float inv = 1.f;
+    if (normalize) {
+      const float nr = row_sumsq(xr, d, lane);
+      if (nr > 0.f) inv = 1.0f / sqrtf(nr);
+    }
+    T* o = out + row * d_out;
+    for (int64_t i = lane; i < d_out; i += 64) o[i] = i < d ? (T)(xr[i] * inv) : (T)0.f;
+  }
+}
+
+static int grid_for_rows(int64_t n) {
+  int64_t g = (n + 3) / 4;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+hipError_t launch_l2_normalize_f32(float* x, int64_t n, int64_t d, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(l2_normalize_f32_kernel, dim3(grid_for_rows(n)), dim3(256), 0, st, x, n, d);
+  return hipGetLastError();
+}
+
+hipError_t launch_rows_to_half(const float* x, int64_t n, int64_t d, int64_t ld_in, void* out, int dtype, int64_t d_out,
+                               int normalize, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  if (dtype == RR_DTYPE_F16)
+    hipLaunchKernelGGL(rows_to_half_kernel<_Float16>, dim3(grid_for_rows(n)), dim3(256), 0, st, x, n, d, ld_in,
+                       (_Float16*)out, d_out, normalize);
+  else if (dtype == RR_DTYPE_BF16)
+    hipLaunchKernelGGL(rows_to_half_kernel<__bf16>, dim3(grid_for_rows(n)), dim3(256), 0, st, x, n, d, ld_in,
+                       (__bf16*)out, d_out, normalize);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+}  // namespace rr

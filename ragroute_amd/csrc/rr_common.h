@@ -1,0 +1,55 @@
+// Shared device/host helpers for the ragroute_amd HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rr {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kQueriesPerBlock = 256;  // one scan launch serves 256 queries (4 waves x 64)
+constexpr int kTileRows = 32;          // corpus rows per MFMA tile
+constexpr int kMaxK = 1024;
+constexpr int kSelectCap = 8192;       // u64 keys sorted in LDS by the select kernels (64 KiB)
+constexpr int kSampleRows = 8192;      // bootstrap sample rows (256 tiles)
+constexpr int kDenseMaxRows = 8192;    // corpora up to this size take the dense path
+constexpr int kChunkGrowth = 8;
+
+// ---- total order on candidates: score descending, then id ascending ---------------------
+// key = ord(score) << 32 | (0xFFFFFFFF - id); larger key = better. key 0 = empty slot
+// (ord(NaN) = 0, so NaN-scored rows are never selected).
+__host__ __device__ inline uint32_t ord_f32(float s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t b = __float_as_uint(s);
+#else
+  union { float f; uint32_t u; } cv; cv.f = s; uint32_t b = cv.u;
+#endif
+  if (s != s) return 0u;
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ inline float unord_f32(uint32_t o) {
+  uint32_t b = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __uint_as_float(b);
+#else
+  union { float f; uint32_t u; } cv; cv.u = b; return cv.f;
+#endif
+}
+__host__ __device__ inline uint64_t make_key(float s, uint32_t id) {
+  return ((uint64_t)ord_f32(s) << 32) | (uint64_t)(0xFFFFFFFFu - id);
+}
+__host__ __device__ inline float key_score(uint64_t k) { return unord_f32((uint32_t)(k >> 32)); }
+__host__ __device__ inline uint32_t key_id(uint64_t k) { return 0xFFFFFFFFu - (uint32_t)k; }
+
+// candidate-buffer capacity per (workgroup, query, lane-half) for a given k
+__host__ __device__ inline int cand_cap_for_k(int k) {
+  int c = 2 * k;
+  if (c < k + 32) c = k + 32;
+  return (c + 63) & ~63;
+}
+
+}  // namespace rr

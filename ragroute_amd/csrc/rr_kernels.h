@@ -1,0 +1,55 @@
+// Internal launch interface between the kernel translation units and the C-ABI (capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ragroute_hip.h"
+
+namespace rr {
+
+struct ScanArgs {
+  const void* xb;       // [n_rows][D] f16/bf16 corpus (D = padded dim)
+  const void* xq;       // [nq][D] queries, same dtype
+  const float* thr;     // [256] strict thresholds (filter mode)
+  uint64_t* cand;       // [256][grid*2][cap] candidate keys (filter mode)
+  uint32_t* cand_cnt;   // [256][grid*2]
+  uint64_t* scratch;    // [grid*4][cap] per-wave compaction scratch
+  float* dense;         // [256][dense_ld] scores (dense mode)
+  uint32_t n_rows, nq;
+  uint32_t tile_first, tile_stride, n_tiles;  // tile(j) = tile_first + j*tile_stride, j < n_tiles
+  uint32_t dense_ld;
+  int cap, k;
+};
+
+// flat_scan.hip
+hipError_t launch_flat_scan(const ScanArgs& a, int dtype, int D, bool dense, int grid, hipStream_t st);
+int scan_padded_dim(int d);
+
+// select.hip
+struct SelectArgs {
+  float* thr;           // [256]
+  uint64_t* list;       // [256][list_ld] running top-k keys, sorted descending
+  uint32_t* list_cnt;   // [256]
+  const uint64_t* cand; const uint32_t* cand_cnt;  // as ScanArgs
+  const float* dense; uint32_t dense_ld, dense_cols;
+  uint32_t tile_first, tile_stride;  // dense column c <-> row (tile_first + (c/32)*tile_stride)*32 + c%32
+  uint32_t n_rows, nq;
+  uint32_t nbuf, list_ld;
+  int cap, k;
+};
+hipError_t launch_init_state(const SelectArgs& a, hipStream_t st);
+hipError_t launch_dense_select(const SelectArgs& a, bool bootstrap, hipStream_t st);
+hipError_t launch_compact(const SelectArgs& a, hipStream_t st);
+hipError_t launch_finalize(const SelectArgs& a, float* D, int64_t* I, int64_t id_offset, hipStream_t st);
+hipError_t launch_merge_topk(const float* Din, const int64_t* Iin, int nq, int m, int k, int descending,
+                             float* Dout, int64_t* Iout, hipStream_t st);
+
+// prep.hip
+hipError_t launch_l2_normalize_f32(float* x, int64_t n, int64_t d, hipStream_t st);
+hipError_t launch_rows_to_half(const float* x, int64_t n, int64_t d, int64_t ld_in, void* out, int dtype, int64_t d_out,
+                               int normalize, hipStream_t st);
+
+// router.hip
+hipError_t launch_router_mlp(const rr_router_weights* w, const float* xq, int nq, float* logits, uint8_t* mask,
+                             hipStream_t st);
+
+}  // namespace rr

@@ -1,0 +1,152 @@
+"""faiss-shaped flat index whose corpus lives in HBM and whose search is the HIP scan kernel.
+
+Mirrors the operator surface the reference uses from `faiss` (ragroute/data_source.py):
+  index.search(xq: float32[nq,d], k) -> (D float32[nq,k], I int64[nq,k])      data_source.py:158,186,203
+  index.ntotal, index.d
+  normalize_L2(x: float32[n,d])  in place                                       data_source.py:198-199
+PyTorch is used for device memory and streams only; all arithmetic is in libragroute_hip.so.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+_TORCH_DTYPE = {"fp16": torch.float16, "bf16": torch.bfloat16}
+_RR_DTYPE = {"fp16": _lib.RR_DTYPE_F16, "bf16": _lib.RR_DTYPE_BF16}
+
+
+def _stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.RagrouteHipError("ragroute_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+
+
+def normalize_L2(x):
+    """In-place row-wise L2 normalisation (faiss.normalize_L2, data_source.py:198-199).
+    Accepts a C-contiguous float32 numpy array [n,d] (normalised in place through the GPU) or a
+    float32 CUDA tensor (normalised in place on device)."""
+    if isinstance(x, torch.Tensor):
+        if x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous() or x.dim() != 2:
+            raise ValueError("normalize_L2 needs a contiguous float32 CUDA tensor [n,d]")
+        check(lib().rr_l2_normalize_f32(x.data_ptr(), x.shape[0], x.shape[1], _stream_ptr()), "rr_l2_normalize_f32")
+        return
+    if not (isinstance(x, np.ndarray) and x.dtype == np.float32 and x.ndim == 2 and x.flags.c_contiguous):
+        raise ValueError("normalize_L2 needs a C-contiguous float32 array [n,d]")
+    _require_gpu()
+    t = torch.from_numpy(x).cuda()
+    check(lib().rr_l2_normalize_f32(t.data_ptr(), x.shape[0], x.shape[1], _stream_ptr()), "rr_l2_normalize_f32")
+    x[...] = t.cpu().numpy()
+
+
+class FlatIndex:
+    """Exact inner-product index (the role of faiss.IndexFlatIP in the reference).
+
+    metric: "ip" (reference behaviour) or "cosine" (rows and queries L2-normalised on ingest/search,
+    i.e. normalize_L2 + IP as data_source.py:196-203 does for the wikipedia corpora).
+    dtype : "fp16" or "bf16" storage/MFMA input type; scores accumulate in f32.
+    """
+
+    def __init__(self, d, metric="ip", dtype="fp16", device=None):
+        if metric not in ("ip", "cosine"):
+            raise ValueError(f"unknown metric {metric!r}")
+        if dtype not in _TORCH_DTYPE:
+            raise ValueError(f"unknown dtype {dtype!r}")
+        self.d = int(d)
+        self.metric = metric
+        self.dtype = dtype
+        self.dim = lib().rr_padded_dim(self.d)
+        if self.dim < 0:
+            raise _lib.RagrouteHipError(f"embedding dimension {d} is not supported by this build (max 768)")
+        _require_gpu()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.ntotal = 0
+        self._xb = torch.empty((0, self.dim), dtype=_TORCH_DTYPE[dtype], device=self.device)
+        self._ws = {}
+
+    # -- storage -----------------------------------------------------------------------------
+    def reserve(self, n):
+        if n > self._xb.shape[0]:
+            new = torch.empty((n, self.dim), dtype=self._xb.dtype, device=self.device)
+            new[: self.ntotal].copy_(self._xb[: self.ntotal])
+            self._xb = new
+
+    def add(self, x, chunk_rows=1 << 18):
+        """Append rows (float32 numpy [n,d] or CUDA tensor) to the HBM-resident corpus."""
+        n = x.shape[0]
+        if x.shape[1] != self.d:
+            raise ValueError(f"expected rows of dimension {self.d}, got {x.shape[1]}")
+        if self.ntotal + n > self._xb.shape[0]:
+            self.reserve(max(self.ntotal + n, int(self._xb.shape[0] * 1.5)))
+        with torch.cuda.device(self.device):
+            for s in range(0, n, chunk_rows):
+                e = min(n, s + chunk_rows)
+                part = x[s:e]
+                if isinstance(part, np.ndarray):
+                    part = torch.from_numpy(np.ascontiguousarray(part, dtype=np.float32))
+                part = part.to(self.device, dtype=torch.float32).contiguous()
+                out = self._xb[self.ntotal + s : self.ntotal + e]
+                check(lib().rr_rows_to_half(part.data_ptr(), e - s, self.d, self.d, out.data_ptr(), _RR_DTYPE[self.dtype],
+                                            self.dim, int(self.metric == "cosine"), _stream_ptr()), "rr_rows_to_half")
+                del part
+        self.ntotal += n
+
+    def adopt(self, xb_dev, ntotal=None):
+        """Use an existing device matrix [n, dim] of the index dtype as the corpus (no copy)."""
+        if xb_dev.dtype != self._xb.dtype or xb_dev.dim() != 2 or xb_dev.shape[1] != self.dim or not xb_dev.is_contiguous():
+            raise ValueError("adopt() needs a contiguous device matrix [n, rr_padded_dim(d)] of the index dtype")
+        self._xb = xb_dev
+        self.ntotal = int(xb_dev.shape[0] if ntotal is None else ntotal)
+
+    @property
+    def xb(self):
+        return self._xb[: self.ntotal]
+
+    # -- search ------------------------------------------------------------------------------
+    def _workspace(self, k):
+        ws = self._ws.get(k)
+        if ws is None:
+            nbytes = lib().rr_flat_search_workspace_bytes(k)
+            if nbytes == 0:
+                raise ValueError(f"k must be in [1, {_lib.RR_MAX_K}], got {k}")
+            self._ws = {k: torch.empty(nbytes, dtype=torch.uint8, device=self.device)}
+            ws = self._ws[k]
+        return ws
+
+    def prepare_queries(self, xq):
+        """float32 [nq,d] (numpy or tensor) -> device [nq,dim] in the index dtype (normalised for cosine)."""
+        if isinstance(xq, np.ndarray):
+            xq = torch.from_numpy(np.ascontiguousarray(xq, dtype=np.float32))
+        if xq.dim() != 2 or xq.shape[1] != self.d:
+            raise ValueError(f"queries must be [nq,{self.d}]")
+        xq = xq.to(self.device, dtype=torch.float32).contiguous()
+        out = torch.empty((xq.shape[0], self.dim), dtype=self._xb.dtype, device=self.device)
+        check(lib().rr_rows_to_half(xq.data_ptr(), xq.shape[0], self.d, self.d, out.data_ptr(), _RR_DTYPE[self.dtype],
+                                    self.dim, int(self.metric == "cosine"), _stream_ptr()), "rr_rows_to_half")
+        return out
+
+    def search_prepared(self, xq_half, k, id_offset=0, out=None):
+        """Device-to-device search: xq_half [nq,dim] index dtype -> (D f32[nq,k], I i64[nq,k]) CUDA tensors.
+        Enqueued on the current stream, no host synchronisation."""
+        if xq_half.dtype != self._xb.dtype or xq_half.dim() != 2 or xq_half.shape[1] != self.dim or not xq_half.is_contiguous():
+            raise ValueError("search_prepared() needs contiguous [nq, dim] queries of the index dtype")
+        nq = xq_half.shape[0]
+        ws = self._workspace(k)
+        if out is None:
+            D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        else:
+            D, I = out
+        check(lib().rr_flat_search(self._xb.data_ptr(), _RR_DTYPE[self.dtype], self.ntotal, self.dim, xq_half.data_ptr(), nq, k,
+                                   D.data_ptr(), I.data_ptr(), id_offset, ws.data_ptr(), ws.numel(), _stream_ptr()),
+              "rr_flat_search")
+        return D, I
+
+    def search(self, xq, k):
+        """faiss call shape: float32 [nq,d] -> (D float32[nq,k], I int64[nq,k]) numpy arrays."""
+        with torch.cuda.device(self.device):
+            D, I = self.search_prepared(self.prepare_queries(xq), int(k))
+            return D.cpu().numpy(), I.cpu().numpy()

@@ -1,0 +1,141 @@
+"""GPU parity of the flat search (K1/K2) through the C ABI against the CPU oracle.
+Reference call site: ragroute/data_source.py:158,186,203 (index.search)."""
+import numpy as np
+import pytest
+
+from tests.util import assert_topk_close, half_round, int_data
+
+pytestmark = pytest.mark.gpu
+
+
+def _index(gpu, xb, d, **kw):
+    from ragroute_amd.flat_index import FlatIndex
+    idx = FlatIndex(d, device=gpu, **kw)
+    if xb.shape[0]:
+        idx.add(xb)
+    return idx
+
+
+@pytest.mark.parametrize("n,nq,k", [(5000, 256, 32), (100_000, 300, 32), (70_001, 5, 10), (33, 3, 32), (8193, 17, 100)])
+def test_integer_data_bit_exact(gpu, n, nq, k):
+    """Integer-valued embeddings: scores are exact, so ids AND scores must equal the oracle's bit for
+    bit, including the (score desc, id asc) tie rule, across the dense path, the bootstrap and the chunks."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(n + nq + k)
+    xb, xq = int_data(rng, n, 768), int_data(rng, nq, 768)
+    D, I = _index(gpu, xb, 768).search(xq, k)
+    Dref, Iref = O.flat_search_ip(xb, xq, k)
+    assert np.array_equal(I, Iref)
+    assert np.array_equal(D, Dref)
+
+
+def test_gaussian_fp16(gpu):
+    from oracle import oracle as O
+    rng = np.random.default_rng(7)
+    n, nq, d, k = 200_000, 64, 768, 32
+    xb = half_round(rng.standard_normal((n, d)).astype(np.float32) / np.sqrt(d))
+    xq = half_round(rng.standard_normal((nq, d)).astype(np.float32))
+    D, I = _index(gpu, xb, d).search(xq, k)
+    Dref, Iref = O.flat_search_ip(xb, xq, k)
+    S = (xq.astype(np.float64) @ xb.astype(np.float64).T).astype(np.float32)
+    assert_topk_close(D, I, Dref, Iref, S, tol=1e-3)
+    recall = np.mean([len(set(I[q]) & set(Iref[q])) / k for q in range(nq)])
+    assert recall >= 0.999
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("d,k", [(100, 10), (384, 32), (768, 100)])
+def test_dims_and_dtypes(gpu, dtype, d, k):
+    from oracle import oracle as O
+    rng = np.random.default_rng(d + k)
+    n, nq = 30_000, 9
+    xb = half_round(rng.standard_normal((n, d)).astype(np.float32), dtype)
+    xq = half_round(rng.standard_normal((nq, d)).astype(np.float32), dtype)
+    D, I = _index(gpu, xb, d, dtype=dtype).search(xq, k)
+    Dref, Iref = O.flat_search_ip(xb, xq, k)
+    assert_topk_close(D, I, Dref, Iref, None, tol=2e-3 * np.sqrt(d))
+
+
+@pytest.mark.parametrize("n", [0, 1, 31, 32])
+def test_tiny_and_empty(gpu, n):
+    """k > ntotal pads with (-inf, -1) like FAISS; empty index returns only padding."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(n)
+    xb, xq = int_data(rng, n, 768), int_data(rng, 4, 768)
+    D, I = _index(gpu, xb, 768).search(xq, 32)
+    Dref, Iref = O.flat_search_ip(xb.reshape(n, 768), xq, 32)
+    assert np.array_equal(I, Iref) and np.array_equal(D, Dref)
+
+
+def test_no_queries(gpu):
+    idx = _index(gpu, int_data(np.random.default_rng(0), 100, 768), 768)
+    D, I = idx.search(np.zeros((0, 768), np.float32), 5)
+    assert D.shape == (0, 5) and I.shape == (0, 5)
+
+
+def test_sorted_corpus_forces_compaction(gpu):
+    """Adversarial order: scores increase with the row id, so every tile beats every threshold and the
+    per-lane candidate buffers overflow again and again; the exact in-kernel compaction must keep the
+    result identical to the oracle."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(3)
+    n, d, k = 70_000, 768, 32
+    xb = int_data(rng, n, d, -1, 2)
+    xb[:, 0] = np.arange(n) // 40          # <= 1749, exact in fp16
+    xq = np.zeros((3, d), np.float32)
+    xq[0, 0] = 1.0                          # score = row // 40 : ascending with ties
+    xq[1, 0] = -1.0                         # descending: nothing after the first tiles survives
+    xq[2] = int_data(rng, 1, d)[0]
+    D, I = _index(gpu, xb, d).search(xq, k)
+    Dref, Iref = O.flat_search_ip(xb, xq, k)
+    assert np.array_equal(I, Iref) and np.array_equal(D, Dref)
+
+
+def test_all_ties(gpu):
+    """Every score equal: the answer is ids 0..k-1 (ascending-id tie rule), from every code path."""
+    n, d, k = 20_000, 768, 32
+    xb = np.ones((n, d), np.float32)
+    xq = np.ones((2, d), np.float32)
+    D, I = _index(gpu, xb, d).search(xq, k)
+    assert np.array_equal(I, np.tile(np.arange(k), (2, 1)))
+    assert np.array_equal(D, np.full((2, k), 768.0, np.float32))
+
+
+def test_cosine_metric(gpu):
+    from oracle import oracle as O
+    rng = np.random.default_rng(11)
+    n, nq, d, k = 50_000, 8, 768, 10
+    xb = rng.standard_normal((n, d)).astype(np.float32) * rng.uniform(0.1, 10, (n, 1)).astype(np.float32)
+    xq = rng.standard_normal((nq, d)).astype(np.float32) * 3
+    D, I = _index(gpu, xb, d, metric="cosine").search(xq, k)
+    xbn, xqn = xb.copy(), xq.copy()
+    O.normalize_L2(xbn)
+    O.normalize_L2(xqn)
+    Dref, Iref = O.flat_search_ip(half_round(xbn), half_round(xqn), k)
+    assert_topk_close(D, I, Dref, Iref, None, tol=1e-3)
+    assert np.all(D <= 1.0 + 1e-3)
+
+
+def test_batched_equals_single_query(gpu):
+    """The reference searches one query per call (data_source.py:114); a 256-query batch must give each
+    query exactly the result of its own single-query call."""
+    rng = np.random.default_rng(5)
+    n, d, k = 60_000, 768, 32
+    xb = half_round(rng.standard_normal((n, d)).astype(np.float32))
+    xq = half_round(rng.standard_normal((40, d)).astype(np.float32))
+    idx = _index(gpu, xb, d)
+    D, I = idx.search(xq, k)
+    for q in (0, 17, 39):
+        D1, I1 = idx.search(xq[q : q + 1], k)
+        assert np.array_equal(I1[0], I[q]) and np.array_equal(D1[0], D[q])
+
+
+def test_bad_arguments(gpu):
+    from ragroute_amd import RagrouteHipError
+    idx = _index(gpu, int_data(np.random.default_rng(0), 64, 768), 768)
+    with pytest.raises((ValueError, RagrouteHipError)):
+        idx.search(np.zeros((1, 768), np.float32), 0)
+    with pytest.raises((ValueError, RagrouteHipError)):
+        idx.search(np.zeros((1, 768), np.float32), 5000)
+    with pytest.raises(ValueError):
+        idx.search(np.zeros((1, 100), np.float32), 5)
