@@ -70,6 +70,14 @@ size_t rr_flat_search_workspace_bytes(int k);
 int rr_flat_search(const void* d_xb, int dtype, int64_t n_rows, int dim, const void* d_xq, int nq, int k,
                    float* d_D, int64_t* d_I, int64_t id_offset, void* d_ws, size_t ws_bytes, void* stream);
 
+/* Measurement aid (bench.py): between rr_profile_begin and rr_profile_end every launch of the scan
+ * kernel made by rr_flat_search on the calling thread is bracketed by HIP events on the launch stream.
+ * rr_profile_end waits for them and returns the summed kernel time, the number of launches and the
+ * corpus rows they covered.  No reference counterpart (the reference only has time.time() deltas,
+ * data_source.py:104,130). */
+int rr_profile_begin(int max_launches);
+int rr_profile_end(double* scan_ms_total, int* n_launches, double* rows_scanned);
+
 /* Cross-source candidate merge: per query, the k best of m (score, id) candidates.
  * Replaces `np.argsort(scores)[::-1][:k]` / `np.argsort(scores)[:k]` — reference
  * ragroute/rerank.py:3-9 (rerank_medrag) and :28-34 (rerank_wikipedia) — applied to the

@@ -34,6 +34,23 @@ int device_cus() {
   return cached;
 }
 
+// ---- live profiling of the dominant kernel (bench.py roofline) -------------------------------------
+struct ProfEntry { hipEvent_t start, stop; uint64_t rows; };
+thread_local ProfEntry* g_prof = nullptr;
+thread_local int g_prof_cap = 0, g_prof_n = 0;
+
+hipError_t profiled_scan(const rr::ScanArgs& a, int dtype, int D, bool dense, int grid, hipStream_t st) {
+  if (g_prof && g_prof_n < g_prof_cap) {
+    ProfEntry& p = g_prof[g_prof_n++];
+    p.rows = (uint64_t)a.n_tiles * rr::kTileRows;
+    (void)hipEventRecord(p.start, st);
+    hipError_t e = rr::launch_flat_scan(a, dtype, D, dense, grid, st);
+    (void)hipEventRecord(p.stop, st);
+    return e;
+  }
+  return rr::launch_flat_scan(a, dtype, D, dense, grid, st);
+}
+
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
@@ -144,14 +161,14 @@ int rr_flat_search(const void* xb, int dtype, int64_t n_rows, int dim, const voi
     if (n_rows > 0 && n_rows <= kDenseMaxRows) {
       // tiny corpus: all scores, one exact selection
       a.tile_first = 0; a.tile_stride = 1; a.n_tiles = total_tiles;
-      RR_CHECK(launch_flat_scan(a, dtype, dim, true, grid, st), "rr_flat_search/dense");
+      RR_CHECK(profiled_scan(a, dtype, dim, true, grid, st), "rr_flat_search/dense");
       s.tile_first = 0; s.tile_stride = 1; s.dense_cols = total_tiles * kTileRows;
       RR_CHECK(launch_dense_select(s, false, st), "rr_flat_search/dense_select");
     } else if (n_rows > 0) {
       // bootstrap: k-th best score of a strided sample of tiles = a valid lower bound
       const uint32_t n_sample_tiles = kSampleRows / kTileRows;
       a.tile_first = 0; a.tile_stride = total_tiles / n_sample_tiles; a.n_tiles = n_sample_tiles;
-      RR_CHECK(launch_flat_scan(a, dtype, dim, true, grid, st), "rr_flat_search/bootstrap");
+      RR_CHECK(profiled_scan(a, dtype, dim, true, grid, st), "rr_flat_search/bootstrap");
       s.tile_first = 0; s.tile_stride = a.tile_stride; s.dense_cols = kSampleRows;
       RR_CHECK(launch_dense_select(s, true, st), "rr_flat_search/bootstrap_select");
       // chunks [0,e1), [e1,e2), ... with e growing 8x: ~7k survivors per query and chunk
@@ -159,7 +176,7 @@ int rr_flat_search(const void* xb, int dtype, int64_t n_rows, int dim, const voi
       while (begin < total_tiles) {
         if (end > total_tiles) end = total_tiles;
         a.tile_first = (uint32_t)begin; a.tile_stride = 1; a.n_tiles = (uint32_t)(end - begin);
-        RR_CHECK(launch_flat_scan(a, dtype, dim, false, grid, st), "rr_flat_search/scan");
+        RR_CHECK(profiled_scan(a, dtype, dim, false, grid, st), "rr_flat_search/scan");
         RR_CHECK(launch_compact(s, st), "rr_flat_search/compact");
         begin = end;
         end *= kChunkGrowth;
@@ -168,6 +185,40 @@ int rr_flat_search(const void* xb, int dtype, int64_t n_rows, int dim, const voi
     RR_CHECK(launch_finalize(s, D_b, I_b, id_offset, st), "rr_flat_search/finalize");
   }
 #undef RR_CHECK
+  return RR_OK;
+}
+
+int rr_profile_begin(int max_launches) {
+  if (g_prof) return fail(RR_ERR_INVALID, "rr_profile_begin: already profiling%s");
+  if (max_launches < 1) return fail(RR_ERR_INVALID, "rr_profile_begin: max_launches < 1%s");
+  g_prof = new ProfEntry[max_launches];
+  g_prof_cap = 0;
+  g_prof_n = 0;
+  for (int i = 0; i < max_launches; ++i) {
+    if (hipEventCreate(&g_prof[i].start) != hipSuccess || hipEventCreate(&g_prof[i].stop) != hipSuccess)
+      return fail(RR_ERR_HIP, "rr_profile_begin: hipEventCreate failed%s");
+    g_prof_cap = i + 1;
+  }
+  return RR_OK;
+}
+
+int rr_profile_end(double* scan_ms_total, int* n_launches, double* rows_scanned) {
+  if (!g_prof) return fail(RR_ERR_INVALID, "rr_profile_end: not profiling%s");
+  double ms = 0, rows = 0;
+  int n = 0;
+  for (int i = 0; i < g_prof_n; ++i) {
+    float t = 0;
+    if (hipEventSynchronize(g_prof[i].stop) == hipSuccess && hipEventElapsedTime(&t, g_prof[i].start, g_prof[i].stop) == hipSuccess) {
+      ms += t; rows += (double)g_prof[i].rows; ++n;
+    }
+  }
+  for (int i = 0; i < g_prof_cap; ++i) { (void)hipEventDestroy(g_prof[i].start); (void)hipEventDestroy(g_prof[i].stop); }
+  delete[] g_prof;
+  g_prof = nullptr;
+  g_prof_cap = g_prof_n = 0;
+  if (scan_ms_total) *scan_ms_total = ms;
+  if (n_launches) *n_launches = n;
+  if (rows_scanned) *rows_scanned = rows;
   return RR_OK;
 }
 
@@ -183,7 +234,7 @@ int rr_merge_topk(const float* Din, const int64_t* Iin, int nq, int m, int k, in
 
 int rr_router_mlp(const rr_router_weights* w, const float* xq, int nq, float* logits, uint8_t* mask, void* stream) {
   if (!w || nq < 0) return fail(RR_ERR_INVALID, "rr_router_mlp: bad arguments%s");
-  if (w->n_sources < 1 || w->d_max < 1 || w->n_models < 1 || w->d_max > 8192)
+  if (w->n_sources < 1 || w->d_max < 1 || w->n_models < 1 || w->d_max > 9216)
     return fail(RR_ERR_INVALID, "rr_router_mlp: bad weight header%s");
   if (nq == 0) return RR_OK;
   if (!xq || !logits || !mask || !w->w1q || !w->c1 || !w->w2 || !w->w3 || !w->model_of_source)

@@ -1,0 +1,67 @@
+"""CPU: the C-ABI library loads and exports every symbol include/ragroute_hip.h declares; argument
+validation that needs no GPU returns the documented status codes (no compute calls here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "ragroute_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    from ragroute_amd import _lib
+    L = _lib.lib()
+    names = _declared()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/ragroute_hip.h but not exported"
+    assert set(names) == set(_lib.EXPORTS)
+
+
+def test_version_and_padded_dim():
+    from ragroute_amd import _lib
+    L = _lib.lib()
+    assert L.rr_version() >= 100
+    assert [L.rr_padded_dim(d) for d in (1, 100, 128, 129, 768)] == [128, 128, 128, 256, 768]
+    assert L.rr_padded_dim(769) == -2 and L.rr_padded_dim(0) == -1
+
+
+def test_argument_validation_without_gpu():
+    from ragroute_amd import _lib
+    L = _lib.lib()
+    assert L.rr_flat_search(None, 0, 10, 768, None, 1, 0, None, None, 0, None, 0, None) == -1      # k = 0
+    assert b"k must be" in L.rr_last_error()
+    assert L.rr_flat_search(None, 0, 10, 768, None, 1, 2000, None, None, 0, None, 0, None) == -1   # k > 1024
+    assert L.rr_flat_search(None, 7, 10, 768, None, 1, 5, None, None, 0, None, 0, None) == -1      # dtype
+    assert L.rr_flat_search(None, 0, 10, 700, None, 1, 5, None, None, 0, None, 0, None) == -2      # unpadded dim
+    assert L.rr_flat_search(None, 0, 10, 768, None, 0, 5, None, None, 0, None, 0, None) == 0       # nq = 0 is a no-op
+    assert L.rr_merge_topk(None, None, 1, 9000, 5, 1, None, None, None) == -2
+    assert L.rr_merge_topk(None, None, 0, 5, 5, 1, None, None, None) == 0
+    assert L.rr_rows_to_half(None, 1, 8, 4, None, 0, 8, 0, None) == -1
+    assert L.rr_l2_normalize_f32(None, 0, 8, None) == 0
+    assert L.rr_router_mlp(None, None, 1, None, None, None) == -1
+    assert L.rr_flat_search_workspace_bytes(0) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from ragroute_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    try:
+        _lib.lib()
+        raise AssertionError("expected RagrouteHipError")
+    except _lib.RagrouteHipError as e:
+        assert "no CPU fallback" in str(e)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "ragroute_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read().lower(), f

@@ -1,0 +1,105 @@
+"""CPU: host-side logic that needs no device — fc1 folding algebra, shard ids, candidate layout,
+the flat-index file layout, config constants."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import synth_router_case
+
+
+@pytest.mark.parametrize("dataset", ["medrag", "feb4rag", "wikipedia"])
+def test_fold_weights_reproduces_unfolded_router(dataset):
+    """fc1(scaler(features)) == q @ w1q + c1[c] (float64 fold), so folded logits match the golden logits."""
+    from ragroute_amd import config as C
+    from ragroute_amd.router import fold_weights
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "router.json")))[dataset]
+    case = synth_router_case(dataset, g["seed"])
+    d_max, sources, sd = case["d_max"], case["sources"], case["sd"]
+    cen = np.stack([np.pad(case["centroids"][c], (0, d_max - len(case["centroids"][c]))) for c in sources])
+    if dataset == "medrag":
+        ids, n1 = [C.MEDRAG_SOURCE_TO_ID[c] for c in sources], 4
+    elif dataset == "feb4rag":
+        ids, n1 = [C.FEB4RAG_SOURCE_TO_ID[c] for c in sources], 13
+    else:
+        ids, n1 = [int(c) for c in sources], 10
+    mean, scale = case["scaler"] if case["scaler"] is not None else (None, None)
+    w1q, c1 = fold_weights(sd, cen, ids, n1, d_max, mean, scale)
+    assert w1q.shape == (d_max, 256) and c1.shape == (len(sources), 256)
+    for q, want in zip(case["queries"], g["logits"]):
+        rows = []
+        for ci, c in enumerate(sources):
+            e = q[C.EMBEDDING_MODELS_PER_DATA_SOURCE[dataset][c][0]]
+            rows.append(np.pad(e, (0, d_max - len(e))).astype(np.float64) @ w1q + c1[ci])
+        pre = np.stack(rows).astype(np.float32)
+        h = np.maximum(O.layer_norm(pre, sd["ln1.weight"], sd["ln1.bias"]), 0).astype(np.float32)
+        h = np.maximum(O.layer_norm(h @ sd["fc2.weight"].T + sd["fc2.bias"], sd["ln2.weight"], sd["ln2.bias"]), 0).astype(np.float32)
+        logits = (h @ sd["fc3.weight"].T + sd["fc3.bias"]).reshape(-1)
+        assert np.allclose(logits, want, atol=5e-5, rtol=0)
+
+
+def test_global_ids_and_mask():
+    import torch
+    from ragroute_amd import sharded as S
+    gid = S.global_id(5, 123456789)
+    assert S.split_global_id(gid) == (5, 123456789) and gid < 2 ** 63
+    D = torch.arange(6, dtype=torch.float32).reshape(2, 3)
+    I = torch.arange(6, dtype=torch.int64).reshape(2, 3)
+    Dm, Im = S.apply_route_mask(D, I, torch.tensor([True, False]))
+    assert torch.equal(Dm[0], D[0]) and torch.isinf(Dm[1]).all() and (Im[1] == -1).all()
+    Dg, Ig = S.gather_candidates(D, I)  # no process group: identity
+    assert Dg is D and Ig is I
+
+
+def test_flat_index_file_round_trip(tmp_path):
+    from ragroute_amd.data_source import read_faiss_flat_index, write_faiss_flat_index
+    xb = np.random.default_rng(0).standard_normal((37, 24)).astype(np.float32)
+    p = str(tmp_path / "x.index")
+    write_faiss_flat_index(p, xb, "ip")
+    got, metric = read_faiss_flat_index(p)
+    assert metric == "ip" and np.array_equal(got, xb)
+    open(p, "r+b").write(b"IwFl")
+    with pytest.raises(ValueError):
+        read_faiss_flat_index(p)
+
+
+def test_data_source_paths_follow_reference(monkeypatch):
+    from ragroute_amd import config as C
+    from ragroute_amd.data_source import DataSource
+    ds = DataSource(2, "medrag", "textbooks")
+    assert ds.recv_port == C.SERVER_CLIENT_BASE_PORT + 2 and ds.send_port == C.CLIENT_SERVER_BASE_PORT + 2
+    assert ds.index_path.endswith("textbooks/index/ncbi/MedCPT-Article-Encoder/faiss.index")
+    fs = DataSource(0, "feb4rag", "scifact")
+    assert fs.index_path.endswith("embeddings/scifact/scifact_gte-base.faiss")
+    assert fs.doc_ids_path.endswith("scifact_gte-base.docids.json")
+    with pytest.raises(ValueError):
+        DataSource(0, "nope", "x")
+
+
+def test_router_strategies_without_weights():
+    from ragroute_amd import config as C
+    from ragroute_amd.router import Router
+    src = C.DATA_SOURCES["medrag"]
+    assert Router("medrag", src, "all").select_relevant_sources({}) == src
+    assert Router("medrag", src, "none").select_relevant_sources({}) == []
+    assert len(Router("medrag", src, "random").select_relevant_sources({})) == 2
+    assert len(Router("feb4rag", C.DATA_SOURCES["feb4rag"], "random").select_relevant_sources({})) == 9
+    assert Router("medrag", src, "ragroute", simulate=True).select_relevant_sources({}) == src
+    with pytest.raises(ValueError):
+        Router("medrag", src, "bogus").select_relevant_sources({})
+    emb = Router("feb4rag", C.DATA_SOURCES["feb4rag"], "all", simulate=True).encode_query("q")
+    assert len(emb) == 8 and all(v.shape == (4096,) for v in emb.values())
+    r = Router("feb4rag", C.DATA_SOURCES["feb4rag"], "ragroute")
+    x = r.pack_queries({m: np.ones(8, np.float32) for m in r.model_names})
+    assert tuple(x.shape) == (1, 8, 4096) and float(x.sum()) == 64.0
+
+
+def test_rerank_feb4rag_host_path_matches_golden():
+    from ragroute_amd.rerank import rerank_feb4rag
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rerank.json")))["feb4rag"]
+    rel = {q: [tuple(x) for x in v] for q, v in g["relevance"].items()}
+    for c in g["cases"]:
+        d, i = rerank_feb4rag(c["ids"], c["docs"], c["query_id"], c["k"], rel)
+        assert d == c["out_docs"] and i == c["out_ids"]

@@ -1,0 +1,166 @@
+"""GPU parity of the router MLP (K3), the merge (K4), the normalisation (K0) and the data-source glue,
+all through the C ABI, against the oracle and the reference-generated golden vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import half_round, int_data, synth_medrag_corpus, synth_router_case
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+LOGIT_TOL = 2e-4   # f32 re-association of the folded fc1 (K up to 4096) vs the reference's f64 features + torch sgemm
+
+
+def _router(dataset, seed):
+    from ragroute_amd.router import Router
+    case = synth_router_case(dataset, seed)
+    r = Router(dataset, case["sources"], "ragroute")
+    mean, scale = case["scaler"] if case["scaler"] is not None else (None, None)
+    r.set_router(case["sd"], case["centroids"], mean, scale)
+    return r, case
+
+
+@pytest.mark.parametrize("dataset", ["medrag", "feb4rag", "wikipedia"])
+def test_router_matches_reference_golden(gpu, dataset):
+    """Logits within LOGIT_TOL of the reference's; selected sources identical wherever the reference logit is
+    further than LOGIT_TOL from the decision boundary (router.py:276-282)."""
+    g = json.load(open(os.path.join(GOLD, "router.json")))[dataset]
+    r, case = _router(dataset, g["seed"])
+    thr = 0.4924 if dataset == "medrag" else 0.5
+    logit_thr = np.log(thr / (1 - thr))
+    for q, want_logits, want_sel in zip(case["queries"], g["logits"], g["selected"]):
+        logits, mask = r.route_batch(r.pack_queries(q))
+        logits = logits[0].cpu().numpy()
+        assert np.allclose(logits, want_logits, atol=LOGIT_TOL, rtol=0), np.abs(logits - want_logits).max()
+        sel = r.select_relevant_sources(q)
+        for c, wl in zip(case["sources"], want_logits):
+            if abs(wl - logit_thr) > LOGIT_TOL:
+                assert (c in sel) == (c in want_sel)
+        assert sel == [c for c, m in zip(case["sources"], mask[0].cpu().numpy()) if m]
+
+
+def test_router_batch_equals_single(gpu):
+    r, case = _router("feb4rag", 12)
+    names = r.model_names
+    batch = {m: np.stack([np.pad(q[m], (0, 4096 - len(q[m]))) for q in case["queries"]]) for m in names}
+    L, M = r.route_batch(r.pack_queries(batch))
+    for i, q in enumerate(case["queries"]):
+        l1, m1 = r.route_batch(r.pack_queries(q))
+        assert torch.equal(l1[0], L[i]) and torch.equal(m1[0], M[i])
+
+
+def test_router_large_batch_vs_oracle(gpu):
+    """10^4 random rows through the unfolded forward (CorpusRoutingNN.forward) vs the numpy oracle: decision flips
+    only where the logit is within LOGIT_TOL of the boundary."""
+    from oracle import oracle as O
+    from ragroute_amd.router import CorpusRoutingNN
+    case = synth_router_case("medrag", 21)
+    net = CorpusRoutingNN(1540)
+    net.load_state_dict(case["sd"])
+    x = np.random.default_rng(0).standard_normal((10_000, 1540)).astype(np.float32)
+    got = net(x).cpu().numpy().reshape(-1)
+    want = O.corpus_routing_nn(x, case["sd"]).reshape(-1)
+    assert np.abs(got - want).max() < LOGIT_TOL
+    flips = (got > 0) != (want > 0)
+    assert np.all(np.abs(want[flips]) < LOGIT_TOL)
+
+
+def test_merge_topk_vs_oracle(gpu):
+    from oracle import oracle as O
+    from ragroute_amd.rerank import merge_topk
+    rng = np.random.default_rng(1)
+    for nq, m, k in [(256, 256, 32), (256, 800, 100), (3, 1, 4), (5, 4096, 10), (2, 130, 10)]:
+        D = np.round(rng.standard_normal((nq, m)) * 4).astype(np.float32) / 4   # many ties
+        I = np.stack([rng.permutation(10 * m)[:m] for _ in range(nq)]).astype(np.int64) + (7 << 40)
+        I[0, : m // 2] = -1
+        D[-1, 0] = np.nan
+        for desc in (True, False):
+            Dg, Ig = merge_topk(torch.from_numpy(D).cuda(), torch.from_numpy(I).cuda(), k, desc)
+            Io = I.copy()
+            Io[np.isnan(D)] = -1
+            Dr, Ir = O.merge_topk(np.nan_to_num(D), Io, k, desc)
+            assert np.array_equal(Ig.cpu().numpy(), Ir) and np.array_equal(Dg.cpu().numpy(), Dr)
+
+
+def test_rerank_functions_match_reference_golden(gpu):
+    from ragroute_amd import rerank as R
+    g = json.load(open(os.path.join(GOLD, "rerank.json")))
+    for c in g["cases"]:
+        assert list(map(list, R.rerank_medrag(c["docs"], c["scores"], c["k"]))) == c["medrag"]
+        assert list(map(list, R.rerank_wikipedia(c["docs"], c["scores"], c["k"]))) == c["wikipedia"]
+    t = g["ties"]
+    docs, scores = R.rerank_medrag(t["docs"], t["scores"], t["k"])
+    assert scores == t["medrag_scores"] and docs[:2] == ["b", "d"]
+
+
+def test_normalize_l2_and_ingest(gpu):
+    from oracle import oracle as O
+    from ragroute_amd._lib import check, lib
+    from ragroute_amd.flat_index import normalize_L2
+    rng = np.random.default_rng(2)
+    for n, d in [(1, 768), (1000, 768), (37, 100), (5, 4096)]:
+        x = (rng.standard_normal((n, d)) * 3).astype(np.float32)
+        if n > 3:
+            x[3] = 0
+        want = x.copy()
+        O.normalize_L2(want)
+        got = x.copy()
+        normalize_L2(got)
+        assert np.allclose(got, want, atol=1e-6, rtol=1e-6)
+        if n > 3:
+            assert (got[3] == 0).all()
+        xt = torch.from_numpy(x).cuda()
+        for dtype, tdt in ((0, torch.float16), (1, torch.bfloat16)):
+            dim = ((d + 127) // 128) * 128
+            out = torch.full((n, dim), 7, dtype=tdt, device="cuda")
+            check(lib().rr_rows_to_half(xt.data_ptr(), n, d, d, out.data_ptr(), dtype, dim, 1, None), "rows_to_half")
+            torch.cuda.synchronize()
+            ref = torch.from_numpy(want).to(tdt)
+            assert torch.equal(out[:, d:].cpu(), torch.zeros((n, dim - d), dtype=tdt))
+            diff = (out[:, :d].cpu().float() - ref.float()).abs().max().item()
+            assert diff <= (2e-3 if dtype == 0 else 1.6e-2) * float(np.abs(want).max())
+
+
+def test_data_source_glue_matches_reference_golden(gpu, tmp_path, monkeypatch):
+    """retrieve_docs_medrag / retrieve_docs_wikipedia return exactly the tuples the reference's DataSource
+    returned on the same corpus (fixture: tests/golden/data_source_glue.json)."""
+    from oracle import oracle as O
+    from ragroute_amd import config as C
+    from ragroute_amd import data_source as DS
+    g = json.load(open(os.path.join(GOLD, "data_source_glue.json")))
+    xb, metadatas, chunks = synth_medrag_corpus(g["medrag"]["corpus_seed"])
+    monkeypatch.setattr(C, "MEDRAG_DIR", str(tmp_path))
+    monkeypatch.setattr(C, "WIKIPEDIA_DIR", str(tmp_path))
+    ds = DS.DataSource(0, "medrag", "textbooks")
+    os.makedirs(ds.index_dir)
+    os.makedirs(tmp_path / "textbooks" / "chunk")
+    DS.write_faiss_flat_index(ds.index_path, xb)
+    open(ds.doc_ids_path, "w").write("\n".join(json.dumps(m) for m in metadatas))
+    for b, lines in chunks.items():
+        open(tmp_path / "textbooks" / "chunk" / f"{b}.jsonl", "w").write("\n".join(json.dumps(l) for l in lines))
+    ds.load_faiss_index()
+    queries = np.random.default_rng(g["medrag"]["query_seed"]).integers(-2, 3, size=(3, 768)).astype(np.float32)
+    for q, want in zip(queries, g["medrag"]["results"]):
+        indices, docs, scores = ds.retrieve_docs_medrag(q.reshape(1, -1), g["medrag"]["k"])
+        assert indices == want["indices"] and docs == want["docs"] and scores == want["scores"]
+        assert all(isinstance(s, float) for s in scores)
+    # batched form = per-query tuples
+    allres = ds.retrieve_docs_medrag(queries, g["medrag"]["k"])
+    assert [r[0] for r in allres] == [w["indices"] for w in g["medrag"]["results"]]
+    # wikipedia: normalised query, row ids, (title, text) docs
+    n = xb.shape[0]
+    ws = DS.DataSource(3, "wikipedia", "3")
+    xbn = xb.copy()
+    xbn[:, 0] += 3
+    O.normalize_L2(xbn)
+    ws.set_index(half_round(xbn), [], [f"title {i}" for i in range(n)], [f"text {i}" for i in range(n)])
+    for q, want in zip(queries, g["wikipedia"]["results"]):
+        ids, docs, scores = ws.retrieve_docs_wikipedia(q.copy().reshape(1, -1), g["wikipedia"]["k"])
+        assert np.allclose(scores, want["scores"], atol=1e-3)
+        if ids != want["ids"]:   # near-ties may swap within the f32 tolerance
+            assert sorted(ids) == sorted(want["ids"]) or np.min(np.abs(np.diff(want["scores"]))) < 2e-3
+        else:
+            assert [list(d) for d in docs] == want["docs"]

@@ -42,3 +42,47 @@ def assert_topk_close(D, I, Dref, Iref, S=None, tol=1e-3):
                 assert abs(S[q, I[q, j]] - D[q, j]) <= tol
             bad += 1
     return bad
+
+
+# ---- synthetic router cases (shared by tests/golden/make_golden.py and the tests) -----------------
+def synth_router_case(dataset, seed, n_queries=8):
+    """Seeded synthetic router: state_dict, centroids, scaler statistics and query embeddings with the
+    reference's shapes (router.py:32-34, config.py:32-101).  numpy's PCG64 stream is version-stable, so
+    only the seed and the expected outputs need to be stored as fixtures."""
+    from ragroute_amd import config as C
+    rng = np.random.default_rng(seed)
+    d_max = C.EMBEDDING_MAX_LENGTH[dataset]
+    sources = C.DATA_SOURCES[dataset]
+    n_in = C.ROUTER_INPUT_DIMENSION[dataset]
+    u = lambda shape, b: rng.uniform(-b, b, size=shape).astype(np.float32)  # noqa: E731
+    sd = {"fc1.weight": u((256, n_in), 3.0 / np.sqrt(n_in)), "fc1.bias": u((256,), 0.1),
+          "ln1.weight": (1 + 0.2 * rng.standard_normal(256)).astype(np.float32), "ln1.bias": u((256,), 0.2),
+          "fc2.weight": u((128, 256), 2.0 / 16), "fc2.bias": u((128,), 0.1),
+          "ln2.weight": (1 + 0.2 * rng.standard_normal(128)).astype(np.float32), "ln2.bias": u((128,), 0.2),
+          "fc3.weight": u((1, 128), 0.3), "fc3.bias": u((1,), 0.05)}
+    model_dims = {}
+    for s in sources:
+        m = C.EMBEDDING_MODELS_PER_DATA_SOURCE[dataset][s][0]
+        if m not in model_dims:
+            model_dims[m] = d_max if dataset != "feb4rag" else int(rng.choice([768, 1024, 4096]))
+    centroids = {}
+    for s in sources:
+        dm = model_dims[C.EMBEDDING_MODELS_PER_DATA_SOURCE[dataset][s][0]]
+        centroids[s] = (0.5 * rng.standard_normal(dm)).astype(np.float32)
+    scaler = None
+    if dataset in ("medrag", "wikipedia"):
+        scaler = (0.1 * rng.standard_normal(n_in), rng.uniform(0.5, 2.0, size=n_in))
+    queries = [{m: rng.standard_normal(dm).astype(np.float32) for m, dm in model_dims.items()} for _ in range(n_queries)]
+    return {"dataset": dataset, "sources": sources, "sd": sd, "centroids": centroids, "scaler": scaler, "queries": queries,
+            "d_max": d_max}
+
+
+def synth_medrag_corpus(seed, n=600, d=768):
+    """Small integer-valued 'pubmed'-shaped data source: rows, metadatas (row -> {index, source}) and chunk files."""
+    rng = np.random.default_rng(seed)
+    xb = int_data(rng, n, d)
+    books = ["bookA", "bookB", "bookC"]
+    per = n // len(books)
+    metadatas = [{"index": i % per, "source": books[min(i // per, len(books) - 1)]} for i in range(n)]
+    chunks = {b: [{"id": f"{b}_{j}", "title": f"title {b} {j}", "content": f"content of {b} chunk {j}"} for j in range(per + n)] for b in books}
+    return xb, metadatas, chunks
