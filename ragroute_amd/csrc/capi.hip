@@ -3,6 +3,7 @@
 // exact compaction that publishes the next per-query threshold -> finalize.  Everything is
 // enqueued on the caller's stream; nothing here synchronises with the device.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "rr_common.h"
@@ -49,6 +50,23 @@ hipError_t profiled_scan(const rr::ScanArgs& a, int dtype, int D, bool dense, in
     return e;
   }
   return rr::launch_flat_scan(a, dtype, D, dense, grid, st);
+}
+
+// Schedule knobs (defaults from rr_common.h; RR_SAMPLE_ROWS / RR_CHUNK_GROWTH override them for tuning runs)
+int g_sample_rows = rr::kSampleRows, g_chunk_growth = rr::kChunkGrowth;
+void read_schedule_env() {
+  static const bool once = [] {
+    if (const char* v = getenv("RR_SAMPLE_ROWS")) {
+      int r = atoi(v) / rr::kTileRows * rr::kTileRows;
+      if (r >= 1024 && r <= rr::kSampleRows) g_sample_rows = r;
+    }
+    if (const char* v = getenv("RR_CHUNK_GROWTH")) {
+      int g = atoi(v);
+      if (g >= 2 && g <= 1024) g_chunk_growth = g;
+    }
+    return true;
+  }();
+  (void)once;
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -136,6 +154,7 @@ int rr_flat_search(const void* xb, int dtype, int64_t n_rows, int dim, const voi
   Workspace w = carve((char*)ws, k, grid);
   if (ws_bytes < w.total) return fail(RR_ERR_WORKSPACE, "rr_flat_search: workspace smaller than rr_flat_search_workspace_bytes(k)%s");
 
+  read_schedule_env();
   const int cap = cand_cap_for_k(k);
   const uint32_t total_tiles = (uint32_t)((n_rows + kTileRows - 1) / kTileRows);
   hipError_t e;
@@ -166,20 +185,20 @@ int rr_flat_search(const void* xb, int dtype, int64_t n_rows, int dim, const voi
       RR_CHECK(launch_dense_select(s, false, st), "rr_flat_search/dense_select");
     } else if (n_rows > 0) {
       // bootstrap: k-th best score of a strided sample of tiles = a valid lower bound
-      const uint32_t n_sample_tiles = kSampleRows / kTileRows;
+      const uint32_t n_sample_tiles = (uint32_t)g_sample_rows / kTileRows;
       a.tile_first = 0; a.tile_stride = total_tiles / n_sample_tiles; a.n_tiles = n_sample_tiles;
       RR_CHECK(profiled_scan(a, dtype, dim, true, grid, st), "rr_flat_search/bootstrap");
-      s.tile_first = 0; s.tile_stride = a.tile_stride; s.dense_cols = kSampleRows;
+      s.tile_first = 0; s.tile_stride = a.tile_stride; s.dense_cols = (uint32_t)g_sample_rows;
       RR_CHECK(launch_dense_select(s, true, st), "rr_flat_search/bootstrap_select");
       // chunks [0,e1), [e1,e2), ... with e growing 8x: ~7k survivors per query and chunk
-      uint64_t begin = 0, end = (uint64_t)kSampleRows / kTileRows * kChunkGrowth;  // in tiles
+      uint64_t begin = 0, end = (uint64_t)n_sample_tiles * g_chunk_growth;  // in tiles
       while (begin < total_tiles) {
         if (end > total_tiles) end = total_tiles;
         a.tile_first = (uint32_t)begin; a.tile_stride = 1; a.n_tiles = (uint32_t)(end - begin);
         RR_CHECK(profiled_scan(a, dtype, dim, false, grid, st), "rr_flat_search/scan");
         RR_CHECK(launch_compact(s, st), "rr_flat_search/compact");
         begin = end;
-        end *= kChunkGrowth;
+        end *= g_chunk_growth;
       }
     }
     RR_CHECK(launch_finalize(s, D_b, I_b, id_offset, st), "rr_flat_search/finalize");

@@ -17,6 +17,8 @@
 //    to its k best and raises that lane's threshold.  Nothing is ever dropped that could be in
 //    the final top-k (see DESIGN.md "exactness").
 //  * DENSE=true writes every score instead (bootstrap sample and tiny corpora).
+#include <stdlib.h>
+
 #include "rr_common.h"
 #include "rr_kernels.h"
 
@@ -35,6 +37,62 @@ template <> struct Mfma<__bf16> {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
 };
+
+// Inline-asm MFMA: accumulator in VGPRs (the epilogue's VALU reads it there), corpus fragment (A) in VGPRs, query fragment (B) either in AGPRs
+// (block 0) or VGPRs (block 1).  hipcc otherwise keeps part of the resident queries in AGPRs and copies
+// them to VGPRs with v_accvgpr_read before every MFMA (~250 copies per tile).  The accumulate chain
+// (srcC == vDst) needs no wait states; the reader after the chain is fenced by mfma_drain().
+template <typename T> struct MfmaAsm;
+template <> struct MfmaAsm<_Float16> {
+  static __device__ __forceinline__ void first_a(f32x16& c, f16x8 a, f16x8 b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "a"(b));
+  }
+  static __device__ __forceinline__ void acc_a(f32x16& c, f16x8 a, f16x8 b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+  }
+  static __device__ __forceinline__ void acc_v(f32x16& c, f16x8 a, f16x8 b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  }
+};
+template <> struct MfmaAsm<__bf16> {
+  static __device__ __forceinline__ void first_a(f32x16& c, bf16x8 a, bf16x8 b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "a"(b));
+  }
+  static __device__ __forceinline__ void acc_a(f32x16& c, bf16x8 a, bf16x8 b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+  }
+  static __device__ __forceinline__ void acc_v(f32x16& c, bf16x8 a, bf16x8 b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  }
+};
+// Global load of one fragment directly into accumulator registers (gfx90a+ VMEM may target AGPRs).
+template <typename F, typename P>
+__device__ __forceinline__ void agpr_load_frag(F& dst, const P* ptr) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(dst) : "v"(ptr) : "memory");
+}
+// LDS fragment read and counted wait, hidden from hipcc's waitcnt pass on purpose: it answers an asm consumer
+// with lgkmcnt(0), which drains the whole fragment ring.  LDS reads of one wave return in order, so
+// lgkmcnt(N) = "all but the N youngest reads have landed".
+template <typename F>
+__device__ __forceinline__ void lds_read_frag(F& dst, uint32_t addr, int off) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
+}
+// Diagnostic build only (VARIANT 2): shader-clock stamp, fenced so the segment it closes is complete.
+__device__ __forceinline__ uint64_t stamp() {
+  uint64_t t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+// 8-pass XDL result -> any non-MFMA reader needs 18 wait states the compiler cannot see inside asm.
+__device__ __forceinline__ void mfma_drain(f32x16& a0, f32x16& a1) {
+  asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a0), "+v"(a1));
+}
 
 // Wave-cooperative exact compaction of one lane's candidate buffer: keep the k largest keys
 // (sorted, descending) and return the k-th key.  All 64 lanes participate; buf/scratch/cnt are
@@ -61,12 +119,13 @@ __device__ __noinline__ uint64_t wave_compact(uint64_t* buf, uint64_t* scratch, 
   return kth;
 }
 
-template <typename T, int D, bool DENSE>
+template <typename T, int D, bool DENSE, int VARIANT>
 __global__ __launch_bounds__(256, 1) void flat_scan_kernel(const ScanArgs a) {
   typedef typename Mfma<T>::frag frag;
   constexpr int KS = D / 16;  // 16-wide k slices (one MFMA each per query block)
   constexpr int KG = D / 64;  // 64-wide k groups (one 1 KiB DMA piece per 8 rows)
   constexpr int TILE_BYTES = kTileRows * D * 2;
+  constexpr int NA1 = KS < 14 ? KS : 14;  // block-1 query fragments that also live in AGPRs (4*(KS+NA1) <= 248)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
@@ -75,17 +134,39 @@ __global__ __launch_bounds__(256, 1) void flat_scan_kernel(const ScanArgs a) {
   const uint32_t q0i = wave * 64 + r, q1i = q0i + 32;
 
   // ---- resident queries (MFMA B operand: lane holds query r, k = 16 s + 8 h .. +7) ----------
+  // Rows past nq are clamped to the last query (their thresholds are +inf / their dense rows unused).
   frag q0[KS], q1[KS];
   {
     const T* xq = (const T*)a.xq;
-    const T* p0 = xq + (size_t)q0i * D + 8 * h;
-    const T* p1 = xq + (size_t)q1i * D + 8 * h;
-    const bool v0 = q0i < a.nq, v1 = q1i < a.nq;
-    const frag z = {0};
+    const uint32_t r0 = q0i < a.nq ? q0i : a.nq - 1, r1 = q1i < a.nq ? q1i : a.nq - 1;
+    const T* p0 = xq + (size_t)r0 * D + 8 * h;
+    const T* p1 = xq + (size_t)r1 * D + 8 * h;
+    if (VARIANT == 0) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      q0[s] = v0 ? *(const frag*)(p0 + 16 * s) : z;
-      q1[s] = v1 ? *(const frag*)(p1 + 16 * s) : z;
+      for (int s = 0; s < KS; ++s) {
+        q0[s] = *(const frag*)(p0 + 16 * s);
+        q1[s] = *(const frag*)(p1 + 16 * s);
+      }
+    } else {
+      // Block 0 (and the first NA1 fragments of block 1) are loaded STRAIGHT INTO AGPRs, so the values are
+      // accumulator-file class for their whole life and the MFMAs read them there without copies.
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        agpr_load_frag(q0[s], p0 + 16 * s);
+        if (s < NA1) agpr_load_frag(q1[s], p1 + 16 * s);
+        else q1[s] = *(const frag*)(p1 + 16 * s);
+      }
+      // one wait that names every asm-loaded destination, before any consumer (hipcc does not count asm loads)
+#pragma unroll
+      for (int s = 0; s < KS; s += 8) {
+        if (s + 8 <= KS)
+          asm volatile("s_waitcnt vmcnt(0)" : "+a"(q0[s]), "+a"(q0[s + 1]), "+a"(q0[s + 2]), "+a"(q0[s + 3]), "+a"(q0[s + 4]),
+                       "+a"(q0[s + 5]), "+a"(q0[s + 6]), "+a"(q0[s + 7]));
+        else
+          for (int t = s; t < KS; ++t) asm volatile("s_waitcnt vmcnt(0)" : "+a"(q0[t]));
+      }
+#pragma unroll
+      for (int s = 0; s < NA1; ++s) asm volatile("s_waitcnt vmcnt(0)" : "+a"(q1[s]));
     }
   }
 
@@ -112,40 +193,99 @@ __global__ __launch_bounds__(256, 1) void flat_scan_kernel(const ScanArgs a) {
   const int f_w = ((rho_w >> 1) & 3) | ((wave & 1) << 2);
   const int c_w = sig ^ f_w;
 
-  auto issue_tile = [&](uint32_t j, int slot) {
+  // tile ordinal j -> per-lane global source address of this wave's row group (rows clamped into the corpus;
+  // ordinals past the end re-load the last tile, which keeps the vmcnt bookkeeping uniform)
+  auto tile_src = [&](uint32_t j) -> const char* {
+    if (j >= a.n_tiles) j = a.n_tiles - 1;
     const uint32_t tile = a.tile_first + j * a.tile_stride;
     uint32_t row = tile * kTileRows + wave * 8 + rho_w;
     row = row < a.n_rows ? row : a.n_rows - 1;
-    const char* g = (const char*)a.xb + (size_t)row * (D * 2) + c_w * 16;
+    return (const char*)a.xb + (size_t)row * (D * 2) + c_w * 16;
+  };
+  auto issue_piece = [&](const char* g, int slot, int kg) {
     char* l = smem + slot * TILE_BYTES + wave * 1024;
-#pragma unroll
-    for (int kg = 0; kg < KG; ++kg)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + kg * 128),
-                                       (__attribute__((address_space(3))) void*)(l + kg * 4096), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + kg * 128),
+                                     (__attribute__((address_space(3))) void*)(l + kg * 4096), 16, 0, 0);
   };
 
   uint32_t j = blockIdx.x;
   const uint32_t stride = gridDim.x;
   const uint32_t n_tiles = a.n_tiles;
-  if (j < n_tiles) issue_tile(j, 0);
-  if (j + stride < n_tiles) issue_tile(j + stride, 1);
+  if (j < n_tiles) {
+    const char* g0 = tile_src(j);
+    const char* g1 = tile_src(j + stride);
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) issue_piece(g0, 0, kg);
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) issue_piece(g1, 1, kg);
+  }
   int slot = 0;
+  uint64_t seg0 = 0, seg1 = 0, seg2 = 0, seg3 = 0, tA = 0, tB = 0;  // VARIANT 2 only
+  uint64_t c_begin = 0, r_begin = 0;
+  if (VARIANT == 2) {
+    c_begin = __builtin_amdgcn_s_memtime();
+    r_begin = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+  }
   for (; j < n_tiles; j += stride) {
-    if (j + stride < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KG) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (VARIANT == 2) tA = stamp();
+    // tile j landed (this wave's pieces): all but the KG youngest DMA ops are done
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KG) : "memory");
+    if (VARIANT == 2) { tB = stamp(); seg0 += tB - tA; tA = tB; }
     __builtin_amdgcn_s_barrier();
+    if (VARIANT == 2) { tB = stamp(); seg1 += tB - tA; tA = tB; }
     int nslot = slot + 2;
     if (nslot >= 3) nslot -= 3;
-    if (j + 2 * stride < n_tiles) issue_tile(j + 2 * stride, nslot);
+    const char* gn = tile_src(j + 2 * stride);
 
-    f32x16 a0 = {0}, a1 = {0};
+    f32x16 a0, a1;
     const char* base = smem + slot * TILE_BYTES;
+    if (VARIANT == 0) {
+      a0 = f32x16{0};
+      a1 = f32x16{0};
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const frag c = *(const frag*)(base + roff[s & 3] + (s >> 2) * 4096);
-      a0 = Mfma<T>::run(c, q0[s], a0);
-      a1 = Mfma<T>::run(c, q1[s], a1);
+      for (int kg = 0; kg < KG; ++kg) issue_piece(gn, nslot, kg);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const frag c = *(const frag*)(base + roff[s & 3] + (s >> 2) * 4096);
+        a0 = Mfma<T>::run(c, q0[s], a0);
+        a1 = Mfma<T>::run(c, q1[s], a1);
+      }
+    } else {
+      // software-pipelined by hand: NB corpus fragments in flight from LDS (counted lgkmcnt), one DMA piece of
+      // the tile after next issued every 4 k-slices, MFMAs back to back
+      constexpr int NB = KS < 8 ? KS : 8;
+      frag c[NB];
+      uint32_t ab[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ab[i] = (uint32_t)(slot * TILE_BYTES) + roff[i];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) lds_read_frag(c[i], ab[i & 3], (i >> 2) * 4096);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        // reads outstanding now: min(NB, KS - s); the oldest is fragment s
+        if (KS - s >= NB) lgkm_wait<NB - 1>();
+        else if (KS - s == 7) lgkm_wait<6>();
+        else if (KS - s == 6) lgkm_wait<5>();
+        else if (KS - s == 5) lgkm_wait<4>();
+        else if (KS - s == 4) lgkm_wait<3>();
+        else if (KS - s == 3) lgkm_wait<2>();
+        else if (KS - s == 2) lgkm_wait<1>();
+        else lgkm_wait<0>();
+        if (s == 0) {  // srcC = inline 0: no accumulator zero-fill
+          MfmaAsm<T>::first_a(a0, c[0], q0[0]);
+          MfmaAsm<T>::first_a(a1, c[0], q1[0]);
+        } else {
+          MfmaAsm<T>::acc_a(a0, c[s % NB], q0[s]);
+          if (s < NA1) MfmaAsm<T>::acc_a(a1, c[s % NB], q1[s]);
+          else MfmaAsm<T>::acc_v(a1, c[s % NB], q1[s]);
+        }
+        if (s + NB < KS) lds_read_frag(c[s % NB], ab[(s + NB) & 3], ((s + NB) >> 2) * 4096);
+        if ((s & 3) == 1) issue_piece(gn, nslot, s >> 2);
+      }
+      mfma_drain(a0, a1);
     }
+    if (VARIANT == 2) { tB = stamp(); seg2 += tB - tA; tA = tB; }
 
     const uint32_t tile = a.tile_first + j * a.tile_stride;
     if (DENSE) {
@@ -203,27 +343,39 @@ __global__ __launch_bounds__(256, 1) void flat_scan_kernel(const ScanArgs a) {
     }
     slot = slot + 1;
     if (slot >= 3) slot = 0;
+    if (VARIANT == 2) { tB = stamp(); seg3 += tB - tA; }
   }
+  if (VARIANT == 2 && !DENSE && lane == 0) {  // stamps leave through the (otherwise unused) dense buffer only
+    uint64_t* dbg = (uint64_t*)a.dense + (size_t)(blockIdx.x * 4 + wave) * 6;
+    dbg[0] = seg0; dbg[1] = seg1; dbg[2] = seg2; dbg[3] = seg3;
+    dbg[4] = __builtin_amdgcn_s_memtime() - c_begin;
+    dbg[5] = __builtin_amdgcn_s_memrealtime() - r_begin;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
   if (!DENSE) {
     a.cand_cnt[q0i * nbuf + blockIdx.x * 2 + h] = cnt0;
     a.cand_cnt[q1i * nbuf + blockIdx.x * 2 + h] = cnt1;
   }
 }
 
+int g_scan_variant = 1;  // 0 = compiler-scheduled builtin MFMA, 1 = pipelined inline-asm MFMA (default)
+
+template <typename T, int D, bool DENSE, int VARIANT>
+static hipError_t launch_scan_v(const ScanArgs& a, int grid, hipStream_t st) {
+  const size_t lds = 3 * (size_t)kTileRows * D * 2;
+  hipError_t e = hipFuncSetAttribute((const void*)flat_scan_kernel<T, D, DENSE, VARIANT>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((flat_scan_kernel<T, D, DENSE, VARIANT>), dim3(grid), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
 template <typename T, int D>
 static hipError_t launch_scan_t(const ScanArgs& a, bool dense, int grid, hipStream_t st) {
-  const size_t lds = 3 * (size_t)kTileRows * D * 2;
-  hipError_t e;
-  if (dense) {
-    e = hipFuncSetAttribute((const void*)flat_scan_kernel<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((flat_scan_kernel<T, D, true>), dim3(grid), dim3(256), lds, st, a);
-  } else {
-    e = hipFuncSetAttribute((const void*)flat_scan_kernel<T, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((flat_scan_kernel<T, D, false>), dim3(grid), dim3(256), lds, st, a);
-  }
-  return hipGetLastError();
+  if (g_scan_variant == 0)
+    return dense ? launch_scan_v<T, D, true, 0>(a, grid, st) : launch_scan_v<T, D, false, 0>(a, grid, st);
+  if (g_scan_variant == 2 && D == 768 && !dense) return launch_scan_v<T, 768, false, 2>(a, grid, st);
+  return dense ? launch_scan_v<T, D, true, 1>(a, grid, st) : launch_scan_v<T, D, false, 1>(a, grid, st);
 }
 
 template <typename T>
@@ -240,6 +392,11 @@ static hipError_t launch_scan_d(const ScanArgs& a, int D, bool dense, int grid, 
 }
 
 hipError_t launch_flat_scan(const ScanArgs& a, int dtype, int D, bool dense, int grid, hipStream_t st) {
+  static const bool env_read = [] {
+    if (const char* v = getenv("RR_SCAN_VARIANT")) g_scan_variant = atoi(v);
+    return true;
+  }();
+  (void)env_read;
   if (dtype == RR_DTYPE_F16) return launch_scan_d<_Float16>(a, D, dense, grid, st);
   if (dtype == RR_DTYPE_BF16) return launch_scan_d<__bf16>(a, D, dense, grid, st);
   return hipErrorInvalidValue;
