@@ -253,7 +253,7 @@ int rr_merge_topk(const float* Din, const int64_t* Iin, int nq, int m, int k, in
 
 int rr_router_mlp(const rr_router_weights* w, const float* xq, int nq, float* logits, uint8_t* mask, void* stream) {
   if (!w || nq < 0) return fail(RR_ERR_INVALID, "rr_router_mlp: bad arguments%s");
-  if (w->n_sources < 1 || w->d_max < 1 || w->n_models < 1 || w->d_max > 9216)
+  if (w->n_sources < 1 || w->d_max < 1 || w->n_models < 1 || w->d_max > 8448)
     return fail(RR_ERR_INVALID, "rr_router_mlp: bad weight header%s");
   if (nq == 0) return RR_OK;
   if (!xq || !logits || !mask || !w->w1q || !w->c1 || !w->w2 || !w->w3 || !w->model_of_source)

@@ -51,7 +51,71 @@ __global__ void init_state_kernel(SelectArgs a) {
   }
 }
 
-template <bool BOOTSTRAP>
+// Bootstrap threshold: the k-th largest score of the dense sample row, by a 4-pass 8-bit radix select over the
+// 32-bit order keys (LDS histograms).  Only the score matters here (ties and ids are irrelevant for a lower bound).
+__global__ __launch_bounds__(1024) void bootstrap_select_kernel(SelectArgs a) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sel_prefix, sel_k;
+  const uint32_t q = blockIdx.x;
+  if (q >= a.nq) return;
+  const int n = (int)a.dense_cols;
+  constexpr int PER = kSelectCap / 1024;  // keys per thread
+  uint32_t key[PER];
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    const int c = threadIdx.x + e * 1024;
+    uint32_t o = 0;
+    if (c < n) {
+      const uint32_t row = (a.tile_first + (uint32_t)(c >> 5) * a.tile_stride) * kTileRows + (c & 31);
+      const float s = a.dense[(size_t)q * a.dense_ld + c];
+      if (row < a.n_rows) o = ord_f32(s);  // NaN -> 0
+    }
+    key[e] = o;
+  }
+  if (threadIdx.x == 0) { sel_prefix = 0; sel_k = (uint32_t)a.k; }
+  uint32_t mask = 0;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t prefix = sel_prefix;
+#pragma unroll
+    for (int e = 0; e < PER; ++e)
+      if ((key[e] & mask) == prefix) atomicAdd(&hist[(key[e] >> shift) & 255], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {  // one wave: suffix sums over the 256 bins (4 bins per lane), find the bin holding the k-th
+      const int l = threadIdx.x;
+      const uint32_t h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+      uint32_t above = h0 + h1 + h2 + h3;  // becomes: count in lanes strictly above this one
+      uint32_t incl = above;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_down(incl, o, 64);
+        if (l + o < 64) incl += v;
+      }
+      above = incl - above;
+      const uint32_t kk = sel_k;
+      // bins of this lane from high to low: 4l+3, 4l+2, 4l+1, 4l
+      uint32_t c3 = above + h3, c2 = c3 + h2, c1 = c2 + h1, c0 = c1 + h0;
+      int bin = -1; uint32_t before = 0;
+      if (above < kk && kk <= c0) {
+        if (kk <= c3) { bin = 4 * l + 3; before = above; }
+        else if (kk <= c2) { bin = 4 * l + 2; before = c3; }
+        else if (kk <= c1) { bin = 4 * l + 1; before = c2; }
+        else { bin = 4 * l; before = c1; }
+        sel_prefix = prefix | ((uint32_t)bin << shift);
+        sel_k = kk - before;
+      }
+    }
+    mask |= 0xFFu << shift;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const uint32_t kth = sel_prefix;  // ord key of the k-th largest sample score (0 if fewer than k valid rows)
+    if (kth != 0 && a.k <= n) a.thr[q] = next_below(unord_f32(kth));
+  }
+}
+
+// Tiny corpora: full sort of the dense row, the k best go straight to the running list.
 __global__ __launch_bounds__(1024) void dense_select_kernel(SelectArgs a) {
   __shared__ uint64_t keys[kSelectCap];
   const uint32_t q = blockIdx.x;
@@ -69,34 +133,25 @@ __global__ __launch_bounds__(1024) void dense_select_kernel(SelectArgs a) {
   }
   __syncthreads();
   bitonic_sort_desc(keys, np);
-  if (BOOTSTRAP) {
-    if (threadIdx.x == 0 && a.k <= np) {
-      const uint64_t kth = keys[a.k - 1];
-      if ((kth >> 32) != 0) a.thr[q] = next_below(key_score(kth));
-    }
-  } else {
-    for (int i = threadIdx.x; i < a.k; i += blockDim.x) {
-      const uint64_t key = i < np ? keys[i] : 0;
-      a.list[(size_t)q * a.list_ld + i] = key;
-      // the first empty slot (or k) is the count
-      const bool valid = (key >> 32) != 0;
-      const bool next_valid = (i + 1 < a.k) && (i + 1 < np) && ((keys[i + 1] >> 32) != 0);
-      if (valid && !next_valid) a.list_cnt[q] = i + 1;
-    }
+  for (int i = threadIdx.x; i < a.k; i += blockDim.x) {
+    const uint64_t key = i < np ? keys[i] : 0;
+    a.list[(size_t)q * a.list_ld + i] = key;
+    // the first empty slot (or k) is the count
+    const bool valid = (key >> 32) != 0;
+    const bool next_valid = (i + 1 < a.k) && (i + 1 < np) && ((keys[i + 1] >> 32) != 0);
+    if (valid && !next_valid) a.list_cnt[q] = i + 1;
   }
 }
 
 __global__ __launch_bounds__(1024) void compact_kernel(SelectArgs a) {
   __shared__ uint64_t keys[kSelectCap];
-  __shared__ int scan[1024];
+  __shared__ int scan[16];
   const uint32_t q = blockIdx.x;
   if (q >= a.nq) return;
   const int tid = threadIdx.x;
   const int k = a.k, cap = a.cap;
   int fill = (int)a.list_cnt[q];
   for (int i = tid; i < fill; i += blockDim.x) keys[i] = a.list[(size_t)q * a.list_ld + i];
-  int G = (kSelectCap - kMaxK) / cap;  // buffers appended per round; a round always fits after a truncation
-  if (G > 1024) G = 1024;
   auto sort_truncate = [&]() {
     const int np = pow2_ceil(fill < 2 ? 2 : fill);
     for (int i = fill + tid; i < np; i += blockDim.x) keys[i] = 0;
@@ -104,24 +159,57 @@ __global__ __launch_bounds__(1024) void compact_kernel(SelectArgs a) {
     bitonic_sort_desc(keys, np);
     if (fill > k) fill = k;
   };
-  for (uint32_t g0 = 0; g0 < a.nbuf; g0 += G) {
+  // workgroup-wide exclusive scan of one value per thread (wave shuffles + one LDS hop); returns the total
+  auto block_scan = [&](int c, int& offs) -> int {
+    const int lane = tid & 63, w = tid >> 6;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) scan[w] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int i = 0; i < 16; ++i) {
+      const int v = scan[i];
+      if (i < w) base += v;
+      tot += v;
+    }
+    __syncthreads();
+    offs = base + incl - c;
+    return tot;
+  };
+  // fast path: every buffer of this query fits next to the running list (the common case: ~7k survivors)
+  bool done = false;
+  if (a.nbuf <= 1024) {
+    int c = 0;
+    if ((uint32_t)tid < a.nbuf) {
+      c = (int)a.cand_cnt[q * a.nbuf + tid];
+      if (c > cap) c = cap;
+    }
+    int offs;
+    const int tot = block_scan(c, offs);
+    if (fill + tot <= kSelectCap) {
+      const uint64_t* src = a.cand + ((size_t)q * a.nbuf + tid) * cap;
+      for (int e = 0; e < c; ++e) keys[fill + offs + e] = src[e];
+      fill += tot;
+      __syncthreads();
+      done = true;
+    }
+  }
+  int G = (kSelectCap - kMaxK) / cap;  // buffers appended per round; a round always fits after a truncation
+  if (G > 1024) G = 1024;
+  for (uint32_t g0 = 0; !done && g0 < a.nbuf; g0 += G) {
     const uint32_t b = g0 + tid;
     int c = 0;
     if (tid < G && b < a.nbuf) {
       c = (int)a.cand_cnt[q * a.nbuf + b];
       if (c > cap) c = cap;
     }
-    scan[tid] = c;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {  // inclusive Hillis-Steele scan
-      const int v = tid >= d ? scan[tid - d] : 0;
-      __syncthreads();
-      scan[tid] += v;
-      __syncthreads();
-    }
-    const int tot = scan[1023];
-    const int offs = scan[tid] - c;
-    if (tot == 0) { __syncthreads(); continue; }
+    int offs;
+    const int tot = block_scan(c, offs);
+    if (tot == 0) continue;
     if (fill + tot > kSelectCap) sort_truncate();  // uniform: fill and tot are workgroup-uniform
     if (c > 0) {
       const uint64_t* src = a.cand + ((size_t)q * a.nbuf + b) * cap;
@@ -215,8 +303,8 @@ hipError_t launch_init_state(const SelectArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t launch_dense_select(const SelectArgs& a, bool bootstrap, hipStream_t st) {
-  if (bootstrap) hipLaunchKernelGGL(dense_select_kernel<true>, dim3(kQueriesPerBlock), dim3(1024), 0, st, a);
-  else hipLaunchKernelGGL(dense_select_kernel<false>, dim3(kQueriesPerBlock), dim3(1024), 0, st, a);
+  if (bootstrap) hipLaunchKernelGGL(bootstrap_select_kernel, dim3(kQueriesPerBlock), dim3(1024), 0, st, a);
+  else hipLaunchKernelGGL(dense_select_kernel, dim3(kQueriesPerBlock), dim3(1024), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_compact(const SelectArgs& a, hipStream_t st) {
