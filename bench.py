@@ -64,10 +64,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    backend = os.environ.get("RR_BENCH_BACKEND", "nccl")  # "gloo" + RR_BENCH_ONE_DEVICE=1 rehearses N>1 on a 1-GPU box
+    if os.environ.get("RR_BENCH_ONE_DEVICE"):
+        local = 0
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ragroute_amd._lib import check, lib
     from ragroute_amd.flat_index import FlatIndex
@@ -90,9 +96,9 @@ def main():
     C = world
     cen = idx.xb[: min(n, 100_000), :d].float().mean(0)
     if world > 1:
-        cens = [torch.empty_like(cen) for _ in range(world)]
-        dist.all_gather(cens, cen)
-        cen_all = torch.stack(cens).cpu().numpy()
+        cens = torch.empty((world, d), dtype=torch.float32)
+        dist.all_gather_into_tensor(cens if backend != "nccl" else (cens := cens.to(dev)), cen.cpu() if backend != "nccl" else cen)
+        cen_all = cens.cpu().numpy()
     else:
         cen_all = cen[None].cpu().numpy()
     net = CorpusRoutingNN(2 * d + C, seed=0)
@@ -125,7 +131,7 @@ def main():
     scan_ms, n_launch, rows_scanned = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
     check(lib().rr_profile_end(ctypes.byref(scan_ms), ctypes.byref(n_launch), ctypes.byref(rows_scanned)), "rr_profile_end")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -37,6 +37,9 @@ def gather_candidates(D, I, group=None):
     if world == 1:
         return D, I
     B, k = D.shape
+    if D.is_cuda and dist.get_backend(group) == "gloo":  # rehearsal on one box: stage through the host
+        Dc, Ic = gather_candidates(D.cpu(), I.cpu(), group)
+        return Dc.to(D.device), Ic.to(I.device)
     Dg = torch.empty((world * B, k), dtype=D.dtype, device=D.device)
     Ig = torch.empty((world * B, k), dtype=I.dtype, device=I.device)
     dist.all_gather_into_tensor(Dg, D.contiguous(), group=group)
