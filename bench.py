@@ -96,9 +96,10 @@ def main():
     C = world
     cen = idx.xb[: min(n, 100_000), :d].float().mean(0)
     if world > 1:
-        cens = torch.empty((world, d), dtype=torch.float32)
-        dist.all_gather_into_tensor(cens if backend != "nccl" else (cens := cens.to(dev)), cen.cpu() if backend != "nccl" else cen)
-        cen_all = cens.cpu().numpy()
+        on_dev = backend == "nccl"
+        cens = torch.empty(world * d, dtype=torch.float32, device=dev if on_dev else "cpu")
+        dist.all_gather_into_tensor(cens, cen.contiguous().view(-1) if on_dev else cen.cpu().view(-1))
+        cen_all = cens.view(world, d).cpu().numpy()
     else:
         cen_all = cen[None].cpu().numpy()
     net = CorpusRoutingNN(2 * d + C, seed=0)

@@ -146,7 +146,7 @@ int rr_flat_search(const void* xb, int dtype, int64_t n_rows, int dim, const voi
   if (n_rows > 0xFFFFFFE0ll) return fail(RR_ERR_UNSUPPORTED, "rr_flat_search: more than 2^32-32 rows per shard%s");
   if (dtype != RR_DTYPE_F16 && dtype != RR_DTYPE_BF16) return fail(RR_ERR_INVALID, "rr_flat_search: bad dtype%s");
   if (scan_padded_dim(dim) != dim)
-    return fail(RR_ERR_UNSUPPORTED, "rr_flat_search: dim must equal rr_padded_dim(d) (128..768 in this build)%s");
+    return fail(RR_ERR_UNSUPPORTED, "rr_flat_search: dim must equal rr_padded_dim(d)%s");
   if (nq == 0) return RR_OK;
   if (!xq || !D || !I || !ws || (!xb && n_rows > 0)) return fail(RR_ERR_INVALID, "rr_flat_search: null pointer%s");
   const int grid = device_cus();

@@ -119,6 +119,74 @@ __device__ __noinline__ uint64_t wave_compact(uint64_t* buf, uint64_t* scratch, 
   return kth;
 }
 
+// Per-lane filter state: strict thresholds, candidate counts and buffer offsets of the lane's two queries.
+struct LaneState {
+  float thr0, thr1;
+  uint32_t cnt0, cnt1, off0, off1;
+};
+
+// Epilogue of one 32-row tile: a0/a1 hold the lane's 16 corpus rows (m = (i&3) + 8*(i>>2) + 4h) for its query of
+// block 0 / block 1.  DENSE: store every score.  Otherwise: strict-threshold filter, append survivors as order keys
+// to the lane's private buffers, compact exactly when a buffer is nearly full.
+template <bool DENSE>
+__device__ __forceinline__ void tile_epilogue(const ScanArgs& a, LaneState& st, const f32x16& a0, const f32x16& a1, uint32_t j,
+                                              uint32_t q0i, uint32_t q1i, int h, int lane, int wave) {
+    const uint32_t tile = a.tile_first + j * a.tile_stride;
+    if (DENSE) {
+      // column = j*32 + m, m = (i&3) + 8*(i>>2) + 4h
+      float* d0 = a.dense + (size_t)q0i * a.dense_ld + j * kTileRows + 4 * h;
+      float* d1 = a.dense + (size_t)q1i * a.dense_ld + j * kTileRows + 4 * h;
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+        *(f32x4*)(d0 + 8 * i4) = f32x4{a0[4 * i4], a0[4 * i4 + 1], a0[4 * i4 + 2], a0[4 * i4 + 3]};
+        *(f32x4*)(d1 + 8 * i4) = f32x4{a1[4 * i4], a1[4 * i4 + 1], a1[4 * i4 + 2], a1[4 * i4 + 3]};
+      }
+    } else {
+      float m0 = a0[0], m1 = a1[0];
+#pragma unroll
+      for (int i = 1; i < 16; ++i) {
+        m0 = fmaxf(m0, a0[i]);
+        m1 = fmaxf(m1, a1[i]);
+      }
+      if (__builtin_amdgcn_ballot_w64(m0 > st.thr0 || m1 > st.thr1)) {
+        const uint32_t row0 = tile * kTileRows + 4 * h;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const uint32_t id = row0 + (i & 3) + 8 * (i >> 2);
+          if (a0[i] > st.thr0 && id < a.n_rows) {
+            a.cand[(size_t)st.off0 + st.cnt0] = make_key(a0[i], id);
+            ++st.cnt0;
+          }
+          if (a1[i] > st.thr1 && id < a.n_rows) {
+            a.cand[(size_t)st.off1 + st.cnt1] = make_key(a1[i], id);
+            ++st.cnt1;
+          }
+        }
+        // keep >= 16 free slots per buffer; compaction is exact and raises the lane threshold
+        const uint32_t lim = (uint32_t)a.cap - 16u;
+        if (__builtin_amdgcn_ballot_w64(st.cnt0 > lim || st.cnt1 > lim)) {
+          uint64_t* scratch = a.scratch + (size_t)(blockIdx.x * 4 + wave) * a.cap;
+#pragma unroll 1
+          for (int b = 0; b < 2; ++b) {
+            uint64_t mask = __builtin_amdgcn_ballot_w64((b ? st.cnt1 : st.cnt0) > lim);
+            while (mask) {
+              const int L = __builtin_ctzll(mask);
+              mask &= mask - 1;
+              const uint32_t off = __shfl(b ? st.off1 : st.off0, L, 64);
+              const int cnt = (int)__shfl(b ? st.cnt1 : st.cnt0, L, 64);
+              const uint64_t kth = wave_compact(a.cand + (size_t)__builtin_amdgcn_readfirstlane(off), scratch,
+                                                __builtin_amdgcn_readfirstlane(cnt), a.k, lane);
+              if (lane == L) {
+                if (b) { st.cnt1 = a.k; st.thr1 = key_score(kth); }
+                else   { st.cnt0 = a.k; st.thr0 = key_score(kth); }
+              }
+            }
+          }
+        }
+      }
+    }
+}
+
 template <typename T, int D, bool DENSE, int VARIANT>
 __global__ __launch_bounds__(256, 1) void flat_scan_kernel(const ScanArgs a) {
   typedef typename Mfma<T>::frag frag;
@@ -170,14 +238,13 @@ __global__ __launch_bounds__(256, 1) void flat_scan_kernel(const ScanArgs a) {
     }
   }
 
-  float thr0 = 0.f, thr1 = 0.f;
-  uint32_t cnt0 = 0, cnt1 = 0, off0 = 0, off1 = 0;
+  LaneState st = {0.f, 0.f, 0, 0, 0, 0};
   const uint32_t nbuf = gridDim.x * 2;
   if (!DENSE) {
-    thr0 = a.thr[q0i];
-    thr1 = a.thr[q1i];
-    off0 = (q0i * nbuf + blockIdx.x * 2 + h) * (uint32_t)a.cap;
-    off1 = (q1i * nbuf + blockIdx.x * 2 + h) * (uint32_t)a.cap;
+    st.thr0 = a.thr[q0i];
+    st.thr1 = a.thr[q1i];
+    st.off0 = (q0i * nbuf + blockIdx.x * 2 + h) * (uint32_t)a.cap;
+    st.off1 = (q1i * nbuf + blockIdx.x * 2 + h) * (uint32_t)a.cap;
   }
 
   // ---- LDS image addressing -------------------------------------------------------------------
@@ -287,60 +354,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_kernel(const ScanArgs a) {
     }
     if (VARIANT == 2) { tB = stamp(); seg2 += tB - tA; tA = tB; }
 
-    const uint32_t tile = a.tile_first + j * a.tile_stride;
-    if (DENSE) {
-      // column = j*32 + m, m = (i&3) + 8*(i>>2) + 4h
-      float* d0 = a.dense + (size_t)q0i * a.dense_ld + j * kTileRows + 4 * h;
-      float* d1 = a.dense + (size_t)q1i * a.dense_ld + j * kTileRows + 4 * h;
-#pragma unroll
-      for (int i4 = 0; i4 < 4; ++i4) {
-        *(f32x4*)(d0 + 8 * i4) = f32x4{a0[4 * i4], a0[4 * i4 + 1], a0[4 * i4 + 2], a0[4 * i4 + 3]};
-        *(f32x4*)(d1 + 8 * i4) = f32x4{a1[4 * i4], a1[4 * i4 + 1], a1[4 * i4 + 2], a1[4 * i4 + 3]};
-      }
-    } else {
-      float m0 = a0[0], m1 = a1[0];
-#pragma unroll
-      for (int i = 1; i < 16; ++i) {
-        m0 = fmaxf(m0, a0[i]);
-        m1 = fmaxf(m1, a1[i]);
-      }
-      if (__builtin_amdgcn_ballot_w64(m0 > thr0 || m1 > thr1)) {
-        const uint32_t row0 = tile * kTileRows + 4 * h;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const uint32_t id = row0 + (i & 3) + 8 * (i >> 2);
-          if (a0[i] > thr0 && id < a.n_rows) {
-            a.cand[(size_t)off0 + cnt0] = make_key(a0[i], id);
-            ++cnt0;
-          }
-          if (a1[i] > thr1 && id < a.n_rows) {
-            a.cand[(size_t)off1 + cnt1] = make_key(a1[i], id);
-            ++cnt1;
-          }
-        }
-        // keep >= 16 free slots per buffer; compaction is exact and raises the lane threshold
-        const uint32_t lim = (uint32_t)a.cap - 16u;
-        if (__builtin_amdgcn_ballot_w64(cnt0 > lim || cnt1 > lim)) {
-          uint64_t* scratch = a.scratch + (size_t)(blockIdx.x * 4 + wave) * a.cap;
-#pragma unroll 1
-          for (int b = 0; b < 2; ++b) {
-            uint64_t mask = __builtin_amdgcn_ballot_w64((b ? cnt1 : cnt0) > lim);
-            while (mask) {
-              const int L = __builtin_ctzll(mask);
-              mask &= mask - 1;
-              const uint32_t off = __shfl(b ? off1 : off0, L, 64);
-              const int cnt = (int)__shfl(b ? cnt1 : cnt0, L, 64);
-              const uint64_t kth = wave_compact(a.cand + (size_t)__builtin_amdgcn_readfirstlane(off), scratch,
-                                                __builtin_amdgcn_readfirstlane(cnt), a.k, lane);
-              if (lane == L) {
-                if (b) { cnt1 = a.k; thr1 = key_score(kth); }
-                else   { cnt0 = a.k; thr0 = key_score(kth); }
-              }
-            }
-          }
-        }
-      }
-    }
+    tile_epilogue<DENSE>(a, st, a0, a1, j, q0i, q1i, h, lane, wave);
     slot = slot + 1;
     if (slot >= 3) slot = 0;
     if (VARIANT == 2) { tB = stamp(); seg3 += tB - tA; }
@@ -353,9 +367,108 @@ __global__ __launch_bounds__(256, 1) void flat_scan_kernel(const ScanArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
   if (!DENSE) {
-    a.cand_cnt[q0i * nbuf + blockIdx.x * 2 + h] = cnt0;
-    a.cand_cnt[q1i * nbuf + blockIdx.x * 2 + h] = cnt1;
+    a.cand_cnt[q0i * nbuf + blockIdx.x * 2 + h] = st.cnt0;
+    a.cand_cnt[q1i * nbuf + blockIdx.x * 2 + h] = st.cnt1;
   }
+}
+
+// ---- generic embedding dimension (any multiple of 64, e.g. 1024 / 4096 of FeB4RAG, config.py:45-57) ------------
+// Queries no longer fit the register file, so they are re-streamed from L2 per 64-wide K step (each wave loads only
+// its own 64 queries: nothing to share, no LDS hop); the corpus goes global -> registers -> LDS (same XOR-swizzled
+// piece layout as the fast kernel) and is shared by the 4 waves.  Two 32-row tiles per iteration halve the L2
+// traffic of the queries.  Compiler-scheduled (builtin MFMA, __syncthreads); same epilogue, same host schedule.
+template <typename T, bool DENSE>
+__global__ __launch_bounds__(256, 1) void flat_scan_generic_kernel(const ScanArgs a, const int D) {
+  typedef typename Mfma<T>::frag frag;
+  __shared__ __attribute__((aligned(16))) char smem[2][2 * 4096];  // [buffer][tile A | tile B] 32 rows x 128 B each
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const uint32_t q0i = wave * 64 + r, q1i = q0i + 32;
+  LaneState st = {0.f, 0.f, 0, 0, 0, 0};
+  const uint32_t nbuf = gridDim.x * 2;
+  if (!DENSE) {
+    st.thr0 = a.thr[q0i];
+    st.thr1 = a.thr[q1i];
+    st.off0 = (q0i * nbuf + blockIdx.x * 2 + h) * (uint32_t)a.cap;
+    st.off1 = (q1i * nbuf + blockIdx.x * 2 + h) * (uint32_t)a.cap;
+  }
+  const T* xq = (const T*)a.xq;
+  const T* p0 = xq + (size_t)(q0i < a.nq ? q0i : a.nq - 1) * D + 8 * h;
+  const T* p1 = xq + (size_t)(q1i < a.nq ? q1i : a.nq - 1) * D + 8 * h;
+  // read side (MFMA A fragment of slice s: row r, chunk 2s+h)
+  uint32_t roff[4];
+  {
+    const int p = r >> 3, rho = r & 7, f = ((rho >> 1) & 3) | ((p & 1) << 2);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) roff[s4] = p * 1024 + rho * 128 + (((2 * s4 + h) ^ f) * 16);
+  }
+  // write side: thread -> (tile A/B, row, chunk pair)
+  const int tsel = tid >> 7, wrow = (tid >> 2) & 31, cp = tid & 3;
+  uint32_t woff0, woff1;
+  {
+    const int p = wrow >> 3, rho = wrow & 7, f = ((rho >> 1) & 3) | ((p & 1) << 2);
+    woff0 = tsel * 4096 + p * 1024 + rho * 128 + (((2 * cp) ^ f) * 16);
+    woff1 = tsel * 4096 + p * 1024 + rho * 128 + (((2 * cp + 1) ^ f) * 16);
+  }
+  const int KG = D / 64;
+  const uint32_t n_tiles = a.n_tiles;
+  for (uint32_t j = 2 * blockIdx.x; j < n_tiles; j += 2 * gridDim.x) {
+    const bool validB = j + 1 < n_tiles;
+    const uint32_t jsel = tsel ? (validB ? j + 1 : j) : j;
+    uint32_t row = (a.tile_first + jsel * a.tile_stride) * kTileRows + wrow;
+    row = row < a.n_rows ? row : a.n_rows - 1;
+    const char* g = (const char*)a.xb + (size_t)row * ((size_t)D * 2) + cp * 32;
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    uint4 cr0 = *(const uint4*)g, cr1 = *(const uint4*)(g + 16);
+    frag qa[4], qb[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qa[s] = *(const frag*)(p0 + 16 * s);
+      qb[s] = *(const frag*)(p1 + 16 * s);
+    }
+    for (int kg = 0; kg < KG; ++kg) {
+      char* buf = smem[kg & 1];
+      *(uint4*)(buf + woff0) = cr0;
+      *(uint4*)(buf + woff1) = cr1;
+      frag ca[4], cb[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { ca[s] = qa[s]; cb[s] = qb[s]; }
+      __syncthreads();
+      if (kg + 1 < KG) {
+        cr0 = *(const uint4*)(g + (size_t)(kg + 1) * 128);
+        cr1 = *(const uint4*)(g + (size_t)(kg + 1) * 128 + 16);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          qa[s] = *(const frag*)(p0 + (kg + 1) * 64 + 16 * s);
+          qb[s] = *(const frag*)(p1 + (kg + 1) * 64 + 16 * s);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const frag xA = *(const frag*)(buf + roff[s]);
+        const frag xB = *(const frag*)(buf + 4096 + roff[s]);
+        acc00 = Mfma<T>::run(xA, ca[s], acc00);
+        acc01 = Mfma<T>::run(xA, cb[s], acc01);
+        acc10 = Mfma<T>::run(xB, ca[s], acc10);
+        acc11 = Mfma<T>::run(xB, cb[s], acc11);
+      }
+    }
+    __syncthreads();  // the next pair restages buffer 0
+    tile_epilogue<DENSE>(a, st, acc00, acc01, j, q0i, q1i, h, lane, wave);
+    if (validB) tile_epilogue<DENSE>(a, st, acc10, acc11, j + 1, q0i, q1i, h, lane, wave);
+  }
+  if (!DENSE) {
+    a.cand_cnt[q0i * nbuf + blockIdx.x * 2 + h] = st.cnt0;
+    a.cand_cnt[q1i * nbuf + blockIdx.x * 2 + h] = st.cnt1;
+  }
+}
+
+template <typename T>
+static hipError_t launch_scan_generic(const ScanArgs& a, int D, bool dense, int grid, hipStream_t st) {
+  if (dense) hipLaunchKernelGGL((flat_scan_generic_kernel<T, true>), dim3(grid), dim3(256), 0, st, a, D);
+  else hipLaunchKernelGGL((flat_scan_generic_kernel<T, false>), dim3(grid), dim3(256), 0, st, a, D);
+  return hipGetLastError();
 }
 
 int g_scan_variant = 1;  // 0 = compiler-scheduled builtin MFMA, 1 = pipelined inline-asm MFMA (default)
@@ -397,15 +510,22 @@ hipError_t launch_flat_scan(const ScanArgs& a, int dtype, int D, bool dense, int
     return true;
   }();
   (void)env_read;
+  if (D > kMaxResidentDim || g_scan_variant == 3) {  // generic-dimension kernel (also forced by RR_SCAN_VARIANT=3)
+    if (D % 64 != 0) return hipErrorInvalidValue;
+    if (dtype == RR_DTYPE_F16) return launch_scan_generic<_Float16>(a, D, dense, grid, st);
+    if (dtype == RR_DTYPE_BF16) return launch_scan_generic<__bf16>(a, D, dense, grid, st);
+    return hipErrorInvalidValue;
+  }
   if (dtype == RR_DTYPE_F16) return launch_scan_d<_Float16>(a, D, dense, grid, st);
   if (dtype == RR_DTYPE_BF16) return launch_scan_d<__bf16>(a, D, dense, grid, st);
   return hipErrorInvalidValue;
 }
 
 int scan_padded_dim(int d) {
-  static const int dims[] = {128, 256, 384, 512, 640, 768};
+  static const int dims[] = {128, 256, 384, 512, 640, 768};  // query-resident instantiations
   for (int v : dims)
     if (d <= v) return v;
+  if (d <= kMaxDim) return (d + 63) / 64 * 64;  // generic kernel
   return -1;
 }
 

@@ -14,6 +14,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kQueriesPerBlock = 256;  // one scan launch serves 256 queries (4 waves x 64)
 constexpr int kTileRows = 32;          // corpus rows per MFMA tile
 constexpr int kMaxK = 1024;
+constexpr int kMaxResidentDim = 768;   // largest dim whose 256 queries fit the register file
+constexpr int kMaxDim = 8192;
 constexpr int kSelectCap = 8192;       // u64 keys sorted in LDS by the select kernels (64 KiB)
 constexpr int kSampleRows = 8192;      // bootstrap sample rows (256 tiles)
 constexpr int kDenseMaxRows = 8192;    // corpora up to this size take the dense path

@@ -60,7 +60,7 @@ class FlatIndex:
         self.dtype = dtype
         self.dim = lib().rr_padded_dim(self.d)
         if self.dim < 0:
-            raise _lib.RagrouteHipError(f"embedding dimension {d} is not supported by this build (max 768)")
+            raise _lib.RagrouteHipError(f"embedding dimension {d} is not supported (max 8192)")
         _require_gpu()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.ntotal = 0

@@ -28,7 +28,8 @@ def test_version_and_padded_dim():
     L = _lib.lib()
     assert L.rr_version() >= 100
     assert [L.rr_padded_dim(d) for d in (1, 100, 128, 129, 768)] == [128, 128, 128, 256, 768]
-    assert L.rr_padded_dim(769) == -2 and L.rr_padded_dim(0) == -1
+    assert [L.rr_padded_dim(d) for d in (769, 1024, 4096)] == [832, 1024, 4096]
+    assert L.rr_padded_dim(8193) == -2 and L.rr_padded_dim(0) == -1
 
 
 def test_argument_validation_without_gpu():
@@ -39,6 +40,7 @@ def test_argument_validation_without_gpu():
     assert L.rr_flat_search(None, 0, 10, 768, None, 1, 2000, None, None, 0, None, 0, None) == -1   # k > 1024
     assert L.rr_flat_search(None, 7, 10, 768, None, 1, 5, None, None, 0, None, 0, None) == -1      # dtype
     assert L.rr_flat_search(None, 0, 10, 700, None, 1, 5, None, None, 0, None, 0, None) == -2      # unpadded dim
+    assert L.rr_flat_search(None, 0, 10, 1000, None, 1, 5, None, None, 0, None, 0, None) == -2
     assert L.rr_flat_search(None, 0, 10, 768, None, 0, 5, None, None, 0, None, 0, None) == 0       # nq = 0 is a no-op
     assert L.rr_merge_topk(None, None, 1, 9000, 5, 1, None, None, None) == -2
     assert L.rr_merge_topk(None, None, 0, 5, 5, 1, None, None, None) == 0

@@ -44,7 +44,7 @@ def test_gaussian_fp16(gpu):
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
-@pytest.mark.parametrize("d,k", [(100, 10), (384, 32), (768, 100)])
+@pytest.mark.parametrize("d,k", [(100, 10), (384, 32), (768, 100), (800, 10), (1024, 10), (4096, 10)])
 def test_dims_and_dtypes(gpu, dtype, d, k):
     from oracle import oracle as O
     rng = np.random.default_rng(d + k)
@@ -65,6 +65,22 @@ def test_tiny_and_empty(gpu, n):
     D, I = _index(gpu, xb, 768).search(xq, 32)
     Dref, Iref = O.flat_search_ip(xb.reshape(n, 768), xq, 32)
     assert np.array_equal(I, Iref) and np.array_equal(D, Dref)
+
+
+@pytest.mark.parametrize("d", [1024, 4096])
+def test_generic_dimension_bit_exact(gpu, d):
+    """FeB4RAG-sized embeddings (config.py:45-57) take the generic-dimension kernel: integer data, exact parity,
+    across bootstrap + chunks (n > 8192) and with an odd number of tiles."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(d)
+    n = 20_033
+    xb, xq = int_data(rng, n, d, -1, 2), int_data(rng, 20, d, -1, 2)
+    D, I = _index(gpu, xb, d).search(xq, 10)
+    Dref, Iref = O.flat_search_ip(xb, xq, 10)
+    assert np.array_equal(I, Iref) and np.array_equal(D, Dref)
+    D2, I2 = _index(gpu, xb[:700], d).search(xq, 10)      # dense path
+    Dr2, Ir2 = O.flat_search_ip(xb[:700], xq, 10)
+    assert np.array_equal(I2, Ir2) and np.array_equal(D2, Dr2)
 
 
 def test_no_queries(gpu):
