@@ -89,6 +89,8 @@ class DataSource:
         self.mmlu_titles, self.mmlu_texts = [], []
         self.faiss_indexes = None
         self.cache_jsonl = {}
+        self._batcher = None
+        self.batch_window_ms = float(os.environ.get("RAGROUTE_BATCH_WINDOW_MS", 2.0))
 
     # -- loading (data_source.py:69-80) -------------------------------------------------------------
     def load_faiss_index(self):
@@ -175,6 +177,32 @@ class DataSource:
             out.append((rows, docs, D[q][: len(rows)].tolist()))
         return out[0] if single else out
 
+    # -- batched serving ---------------------------------------------------------------
+    def retrieve_batch(self, embeddings, k=None):
+        """One GPU search for a window of queries; returns one (ids, docs, scores) tuple per query."""
+        k = config.K[self.dataset] if k is None else k
+        fn = {"medrag": self.retrieve_docs_medrag, "feb4rag": self.retrieve_docs_fed4rag,
+              "wikipedia": self.retrieve_docs_wikipedia}[self.dataset]
+        batch = np.stack([np.asarray(e, dtype=np.float32).reshape(-1) for e in embeddings])
+        out = fn(batch, k)
+        return [out] if batch.shape[0] == 1 else out
+
+    async def handle_query(self, query_data):
+        """Reply message for one request, in the reference's wire format (data_source.py:123-131).  Concurrent
+        requests are coalesced by the batcher into one scan of up to 256 queries."""
+        import asyncio
+        start_time = time.time()
+        if self.simulate:
+            ids, docs, scores = ["doc1", "doc2", "doc3"], ["Document 1 content", "Document 2 content", "Document 3 content"], [0.9, 0.85, 0.8]
+            await asyncio.sleep(config.DATA_SOURCE_DELAY)
+        else:
+            if self._batcher is None:
+                from .queue_manager import QueryBatcher
+                self._batcher = QueryBatcher(self.retrieve_batch, max_batch=256, max_wait_ms=self.batch_window_ms)
+            ids, docs, scores = await self._batcher.submit(query_data["embedding"])
+        return {"query_id": query_data["id"], "client_id": self.client_id, "name": self.name, "indices": ids, "docs": docs,
+                "scores": scores, "duration": time.time() - start_time}
+
     # -- service loop (transport glue; needs pyzmq like the reference) ----------------------------------
     async def start(self):  # pragma: no cover - needs pyzmq
         import asyncio
@@ -188,24 +216,15 @@ class DataSource:
         sender.connect(f"tcp://localhost:{self.send_port}")
         if not self.simulate and self.faiss_indexes is None:
             self.load_faiss_index()
-        k = config.K[self.dataset]
+
+        async def reply(query_data):
+            try:
+                await sender.send_json(await self.handle_query(query_data))
+            except Exception as e:  # logged and dropped, as data_source.py:137-138
+                logger.error(f"Error when fetching documents from data source {self.name} (query data: {query_data}): {e}")
         try:
             while self.running:
-                query_data = await receiver.recv_json()
-                start_time = time.time()
-                try:
-                    if self.simulate:
-                        ids, docs, scores = ["doc1", "doc2", "doc3"], ["Document 1 content", "Document 2 content", "Document 3 content"], [0.9, 0.85, 0.8]
-                        await asyncio.sleep(config.DATA_SOURCE_DELAY)
-                    else:
-                        embedding = np.array(query_data["embedding"], dtype=np.float32).reshape(1, -1)
-                        fn = {"medrag": self.retrieve_docs_medrag, "feb4rag": self.retrieve_docs_fed4rag,
-                              "wikipedia": self.retrieve_docs_wikipedia}[self.dataset]
-                        ids, docs, scores = fn(embedding, k)
-                    await sender.send_json({"query_id": query_data["id"], "client_id": self.client_id, "name": self.name,
-                                            "indices": ids, "docs": docs, "scores": scores, "duration": time.time() - start_time})
-                except Exception as e:  # logged and dropped, as data_source.py:137-138
-                    logger.error(f"Error when fetching documents from data source {self.name} (query data: {query_data}): {e}")
+                asyncio.ensure_future(reply(await receiver.recv_json()))
         finally:
             receiver.close()
             sender.close()

@@ -164,3 +164,25 @@ def test_data_source_glue_matches_reference_golden(gpu, tmp_path, monkeypatch):
             assert sorted(ids) == sorted(want["ids"]) or np.min(np.abs(np.diff(want["scores"]))) < 2e-3
         else:
             assert [list(d) for d in docs] == want["docs"]
+
+
+def test_batched_serving_equals_per_query_replies(gpu):
+    """40 concurrent requests through DataSource.handle_query are coalesced into a few GPU batches and every reply
+    equals the single-query retrieve of the reference call shape (data_source.py:113-132)."""
+    import asyncio
+    from ragroute_amd import data_source as DS
+    xb, metadatas, chunks = synth_medrag_corpus(5)
+    ds = DS.DataSource(0, "medrag", "textbooks")
+    ds.set_index(xb, metadatas)
+    ds.cache_jsonl = {b: [json.dumps(l) for l in lines] for b, lines in chunks.items()}
+    queries = np.random.default_rng(1).integers(-2, 3, size=(40, 768)).astype(np.float32)
+
+    async def go():
+        return await asyncio.gather(*[ds.handle_query({"id": f"q{i}", "embedding": q.tolist()}) for i, q in enumerate(queries)])
+    replies = asyncio.run(go())
+    assert ds._batcher.items_run == 40 and ds._batcher.batches_run <= 4
+    for i, (q, rep) in enumerate(zip(queries, replies)):
+        ids, docs, scores = ds.retrieve_docs_medrag(q.reshape(1, -1), 32)
+        assert rep["query_id"] == f"q{i}" and rep["client_id"] == 0 and rep["name"] == "textbooks"
+        assert rep["indices"] == ids and rep["docs"] == docs and rep["scores"] == scores
+        json.dumps(rep)  # wire format must be JSON-serialisable
