@@ -109,8 +109,7 @@ def main():
     def step():
         _, mask = router.run(xq_router)                                    # K3
         xqh = idx.prepare_queries(xq)                                      # K0 (f32 -> fp16 rows)
-        D, I = idx.search_prepared(xqh, k, id_offset=rank << SHARD_SHIFT)  # K1/K2
-        D, I = apply_route_mask(D, I, mask[:, rank])
+        D, I = idx.search_prepared(xqh, k, id_offset=rank << SHARD_SHIFT, route_mask=mask[:, rank])  # K1/K2 + route mask
         Dg, Ig = gather_candidates(D, I)                                   # RCCL all_gather (N > 1)
         return merge_topk(Dg, Ig, k, True)                                 # K4
 

@@ -66,10 +66,15 @@ size_t rr_flat_search_workspace_bytes(int k);
  *   d_D      device f32 [nq][k]  scores (inner products, f32 accumulation)
  *   d_I      device i64 [nq][k]  row ids + id_offset (shard base), or -1
  *   d_ws     device workspace of at least rr_flat_search_workspace_bytes(k) bytes
+ *   d_route_mask  optional device u8, one byte per query at d_route_mask[q * mask_stride]: 0 means the router
+ *            did not select this source for query q (router.py:282 keeps only selected sources; the front-end
+ *            then never asks this data source, http_server.py:181-209) and the query's result is all padding.
+ *            NULL = every query is served.
  * Any nq >= 0 is accepted (served in blocks of RR_QUERY_BLOCK); each query's result is the same
  * as that of a single-query call, as the reference issues them (data_source.py:114). */
 int rr_flat_search(const void* d_xb, int dtype, int64_t n_rows, int dim, const void* d_xq, int nq, int k,
-                   float* d_D, int64_t* d_I, int64_t id_offset, void* d_ws, size_t ws_bytes, void* stream);
+                   float* d_D, int64_t* d_I, int64_t id_offset, void* d_ws, size_t ws_bytes,
+                   const uint8_t* d_route_mask, int64_t mask_stride, void* stream);
 
 /* Measurement aid (bench.py): between rr_profile_begin and rr_profile_end every launch of the scan
  * kernel made by rr_flat_search on the calling thread is bracketed by HIP events on the launch stream.

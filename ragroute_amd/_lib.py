@@ -52,7 +52,7 @@ def lib():
         L.rr_rows_to_half.argtypes = [vp, i64, i64, i64, vp, i32, i64, i32, vp]
         L.rr_flat_search_workspace_bytes.argtypes = [i32]
         L.rr_flat_search_workspace_bytes.restype = sz
-        L.rr_flat_search.argtypes = [vp, i32, i64, i32, vp, i32, i32, vp, vp, i64, vp, sz, vp]
+        L.rr_flat_search.argtypes = [vp, i32, i64, i32, vp, i32, i32, vp, vp, i64, vp, sz, vp, i64, vp]
         L.rr_merge_topk.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
         L.rr_router_mlp.argtypes = [ctypes.POINTER(RouterWeightsStruct), vp, i32, vp, vp, vp]
         L.rr_profile_begin.argtypes = [i32]

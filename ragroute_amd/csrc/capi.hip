@@ -138,7 +138,8 @@ size_t rr_flat_search_workspace_bytes(int k) {
 }
 
 int rr_flat_search(const void* xb, int dtype, int64_t n_rows, int dim, const void* xq, int nq, int k, float* D,
-                   int64_t* I, int64_t id_offset, void* ws, size_t ws_bytes, void* stream) {
+                   int64_t* I, int64_t id_offset, void* ws, size_t ws_bytes, const uint8_t* route_mask,
+                   int64_t mask_stride, void* stream) {
   using namespace rr;
   hipStream_t st = (hipStream_t)stream;
   if (k < 1 || k > kMaxK) return fail(RR_ERR_INVALID, "rr_flat_search: k must be in [1, 1024]%s");
@@ -201,7 +202,8 @@ int rr_flat_search(const void* xb, int dtype, int64_t n_rows, int dim, const voi
         end *= g_chunk_growth;
       }
     }
-    RR_CHECK(launch_finalize(s, D_b, I_b, id_offset, st), "rr_flat_search/finalize");
+    RR_CHECK(launch_finalize(s, D_b, I_b, id_offset, route_mask ? route_mask + (size_t)qb * mask_stride : nullptr, mask_stride, st),
+             "rr_flat_search/finalize");
   }
 #undef RR_CHECK
   return RR_OK;

@@ -119,6 +119,14 @@ __device__ __noinline__ uint64_t wave_compact(uint64_t* buf, uint64_t* scratch, 
   return kth;
 }
 
+// max without the canonicalising v_max(x,x) hipcc puts in front of fmaxf on MFMA results (NaN operands lose, as maxNum)
+__device__ __forceinline__ float max4(float a, float b, float c, float d) {
+  float t, r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(a), "v"(b), "v"(c));
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(d));
+  return r;
+}
+
 // Per-lane filter state: strict thresholds, candidate counts and buffer offsets of the lane's two queries.
 struct LaneState {
   float thr0, thr1;
@@ -142,24 +150,39 @@ __device__ __forceinline__ void tile_epilogue(const ScanArgs& a, LaneState& st, 
         *(f32x4*)(d1 + 8 * i4) = f32x4{a1[4 * i4], a1[4 * i4 + 1], a1[4 * i4 + 2], a1[4 * i4 + 3]};
       }
     } else {
-      float m0 = a0[0], m1 = a1[0];
+      // two-level test: maxima of the four 4-register groups (rows 8g+4h .. +3), then their maximum
+      float g0[4], g1[4];
 #pragma unroll
-      for (int i = 1; i < 16; ++i) {
-        m0 = fmaxf(m0, a0[i]);
-        m1 = fmaxf(m1, a1[i]);
+      for (int g = 0; g < 4; ++g) {
+        g0[g] = max4(a0[4 * g], a0[4 * g + 1], a0[4 * g + 2], a0[4 * g + 3]);
+        g1[g] = max4(a1[4 * g], a1[4 * g + 1], a1[4 * g + 2], a1[4 * g + 3]);
       }
+      const float m0 = max4(g0[0], g0[1], g0[2], g0[3]);
+      const float m1 = max4(g1[0], g1[1], g1[2], g1[3]);
       if (__builtin_amdgcn_ballot_w64(m0 > st.thr0 || m1 > st.thr1)) {
+        // rare: a typical hit is ONE lane with ONE score, so only the group that holds it is expanded
         const uint32_t row0 = tile * kTileRows + 4 * h;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const uint32_t id = row0 + (i & 3) + 8 * (i >> 2);
-          if (a0[i] > st.thr0 && id < a.n_rows) {
-            a.cand[(size_t)st.off0 + st.cnt0] = make_key(a0[i], id);
-            ++st.cnt0;
+        for (int g = 0; g < 4; ++g) {
+          if (__builtin_amdgcn_ballot_w64(g0[g] > st.thr0)) {
+#pragma unroll
+            for (int i = 4 * g; i < 4 * g + 4; ++i) {
+              const uint32_t id = row0 + (i & 3) + 8 * (i >> 2);
+              if (a0[i] > st.thr0 && id < a.n_rows) {
+                a.cand[(size_t)st.off0 + st.cnt0] = make_key(a0[i], id);
+                ++st.cnt0;
+              }
+            }
           }
-          if (a1[i] > st.thr1 && id < a.n_rows) {
-            a.cand[(size_t)st.off1 + st.cnt1] = make_key(a1[i], id);
-            ++st.cnt1;
+          if (__builtin_amdgcn_ballot_w64(g1[g] > st.thr1)) {
+#pragma unroll
+            for (int i = 4 * g; i < 4 * g + 4; ++i) {
+              const uint32_t id = row0 + (i & 3) + 8 * (i >> 2);
+              if (a1[i] > st.thr1 && id < a.n_rows) {
+                a.cand[(size_t)st.off1 + st.cnt1] = make_key(a1[i], id);
+                ++st.cnt1;
+              }
+            }
           }
         }
         // keep >= 16 free slots per buffer; compaction is exact and raises the lane threshold

@@ -39,7 +39,8 @@ struct SelectArgs {
 hipError_t launch_init_state(const SelectArgs& a, hipStream_t st);
 hipError_t launch_dense_select(const SelectArgs& a, bool bootstrap, hipStream_t st);
 hipError_t launch_compact(const SelectArgs& a, hipStream_t st);
-hipError_t launch_finalize(const SelectArgs& a, float* D, int64_t* I, int64_t id_offset, hipStream_t st);
+hipError_t launch_finalize(const SelectArgs& a, float* D, int64_t* I, int64_t id_offset, const uint8_t* mask, int64_t mask_stride,
+                           hipStream_t st);
 hipError_t launch_merge_topk(const float* Din, const int64_t* Iin, int nq, int m, int k, int descending,
                              float* Dout, int64_t* Iout, hipStream_t st);
 

@@ -227,10 +227,10 @@ __global__ __launch_bounds__(1024) void compact_kernel(SelectArgs a) {
   }
 }
 
-__global__ void finalize_kernel(SelectArgs a, float* D, int64_t* I, int64_t id_offset) {
+__global__ void finalize_kernel(SelectArgs a, float* D, int64_t* I, int64_t id_offset, const uint8_t* mask, int64_t mask_stride) {
   const uint32_t q = blockIdx.x;
   if (q >= a.nq) return;
-  const int cnt = (int)a.list_cnt[q];
+  const int cnt = (mask && !mask[(size_t)q * mask_stride]) ? 0 : (int)a.list_cnt[q];
   for (int i = threadIdx.x; i < a.k; i += blockDim.x) {
     float s = -__builtin_inff();
     int64_t id = -1;
@@ -311,8 +311,9 @@ hipError_t launch_compact(const SelectArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(compact_kernel, dim3(kQueriesPerBlock), dim3(1024), 0, st, a);
   return hipGetLastError();
 }
-hipError_t launch_finalize(const SelectArgs& a, float* D, int64_t* I, int64_t id_offset, hipStream_t st) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(kQueriesPerBlock), dim3(256), 0, st, a, D, I, id_offset);
+hipError_t launch_finalize(const SelectArgs& a, float* D, int64_t* I, int64_t id_offset, const uint8_t* mask, int64_t mask_stride,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(finalize_kernel, dim3(kQueriesPerBlock), dim3(256), 0, st, a, D, I, id_offset, mask, mask_stride);
   return hipGetLastError();
 }
 hipError_t launch_merge_topk(const float* Din, const int64_t* Iin, int nq, int m, int k, int descending, float* Dout,

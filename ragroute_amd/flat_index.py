@@ -128,9 +128,10 @@ class FlatIndex:
                                     self.dim, int(self.metric == "cosine"), _stream_ptr()), "rr_rows_to_half")
         return out
 
-    def search_prepared(self, xq_half, k, id_offset=0, out=None):
+    def search_prepared(self, xq_half, k, id_offset=0, out=None, route_mask=None):
         """Device-to-device search: xq_half [nq,dim] index dtype -> (D f32[nq,k], I i64[nq,k]) CUDA tensors.
-        Enqueued on the current stream, no host synchronisation."""
+        route_mask: optional bool/uint8 CUDA tensor [nq] (may be a strided column of the router's [nq,C] mask):
+        queries with a zero entry get an all-padding result.  Enqueued on the current stream, no host sync."""
         if xq_half.dtype != self._xb.dtype or xq_half.dim() != 2 or xq_half.shape[1] != self.dim or not xq_half.is_contiguous():
             raise ValueError("search_prepared() needs contiguous [nq, dim] queries of the index dtype")
         nq = xq_half.shape[0]
@@ -140,8 +141,13 @@ class FlatIndex:
             I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         else:
             D, I = out
+        mptr, mstride = None, 0
+        if route_mask is not None:
+            if route_mask.dtype not in (torch.bool, torch.uint8) or route_mask.dim() != 1 or route_mask.shape[0] != nq or not route_mask.is_cuda:
+                raise ValueError("route_mask must be a bool/uint8 CUDA vector with one entry per query")
+            mptr, mstride = route_mask.data_ptr(), route_mask.stride(0)
         check(lib().rr_flat_search(self._xb.data_ptr(), _RR_DTYPE[self.dtype], self.ntotal, self.dim, xq_half.data_ptr(), nq, k,
-                                   D.data_ptr(), I.data_ptr(), id_offset, ws.data_ptr(), ws.numel(), _stream_ptr()),
+                                   D.data_ptr(), I.data_ptr(), id_offset, ws.data_ptr(), ws.numel(), mptr, mstride, _stream_ptr()),
               "rr_flat_search")
         return D, I
 

@@ -150,7 +150,7 @@ class FoldedRouter:
         mask = torch.empty((nq, self.n_sources), dtype=torch.uint8, device=self.device)
         check(lib().rr_router_mlp(ctypes.byref(self.struct), xq.data_ptr(), nq, logits.data_ptr(), mask.data_ptr(), _stream_ptr()),
               "rr_router_mlp")
-        return logits, mask.bool()
+        return logits, mask.view(torch.bool)
 
 
 class Router:

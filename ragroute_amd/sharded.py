@@ -63,9 +63,8 @@ class ShardedFlatSearch:
         route_mask: optional bool [B, n_total_shards] (router output)."""
         Ds, Is = [], []
         for idx, sid in zip(self.shards, self.shard_ids):
-            D, I = idx.search_prepared(xq_half, k, id_offset=sid << SHARD_SHIFT)
-            if route_mask is not None:
-                D, I = apply_route_mask(D, I, route_mask[:, sid])
+            D, I = idx.search_prepared(xq_half, k, id_offset=sid << SHARD_SHIFT,
+                                       route_mask=None if route_mask is None else route_mask[:, sid])
             Ds.append(D)
             Is.append(I)
         return (Ds[0], Is[0]) if len(Ds) == 1 else (torch.cat(Ds, 1), torch.cat(Is, 1))

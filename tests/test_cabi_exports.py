@@ -35,13 +35,13 @@ def test_version_and_padded_dim():
 def test_argument_validation_without_gpu():
     from ragroute_amd import _lib
     L = _lib.lib()
-    assert L.rr_flat_search(None, 0, 10, 768, None, 1, 0, None, None, 0, None, 0, None) == -1      # k = 0
+    assert L.rr_flat_search(None, 0, 10, 768, None, 1, 0, None, None, 0, None, 0, None, 0, None) == -1      # k = 0
     assert b"k must be" in L.rr_last_error()
-    assert L.rr_flat_search(None, 0, 10, 768, None, 1, 2000, None, None, 0, None, 0, None) == -1   # k > 1024
-    assert L.rr_flat_search(None, 7, 10, 768, None, 1, 5, None, None, 0, None, 0, None) == -1      # dtype
-    assert L.rr_flat_search(None, 0, 10, 700, None, 1, 5, None, None, 0, None, 0, None) == -2      # unpadded dim
-    assert L.rr_flat_search(None, 0, 10, 1000, None, 1, 5, None, None, 0, None, 0, None) == -2
-    assert L.rr_flat_search(None, 0, 10, 768, None, 0, 5, None, None, 0, None, 0, None) == 0       # nq = 0 is a no-op
+    assert L.rr_flat_search(None, 0, 10, 768, None, 1, 2000, None, None, 0, None, 0, None, 0, None) == -1   # k > 1024
+    assert L.rr_flat_search(None, 7, 10, 768, None, 1, 5, None, None, 0, None, 0, None, 0, None) == -1      # dtype
+    assert L.rr_flat_search(None, 0, 10, 700, None, 1, 5, None, None, 0, None, 0, None, 0, None) == -2      # unpadded dim
+    assert L.rr_flat_search(None, 0, 10, 1000, None, 1, 5, None, None, 0, None, 0, None, 0, None) == -2
+    assert L.rr_flat_search(None, 0, 10, 768, None, 0, 5, None, None, 0, None, 0, None, 0, None) == 0       # nq = 0 is a no-op
     assert L.rr_merge_topk(None, None, 1, 9000, 5, 1, None, None, None) == -2
     assert L.rr_merge_topk(None, None, 0, 5, 5, 1, None, None, None) == 0
     assert L.rr_rows_to_half(None, 1, 8, 4, None, 0, 8, 0, None) == -1
