@@ -15,6 +15,8 @@ def build(force=False, verbose=False):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-o", LIB_PATH] + srcs
+    if os.environ.get("RR_ABLATION_VARIANTS"):
+        cmd.insert(1, "-DRR_ABLATION_VARIANTS")
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout, res.stderr)

@@ -91,10 +91,10 @@ Workspace carve(char* base, int k, int grid) {
   w.thr = (float*)take(kQueriesPerBlock * sizeof(float));
   w.list_cnt = (uint32_t*)take(kQueriesPerBlock * sizeof(uint32_t));
   w.list = (uint64_t*)take((size_t)kQueriesPerBlock * kMaxK * sizeof(uint64_t));
-  w.cand_cnt = (uint32_t*)take((size_t)kQueriesPerBlock * grid * 2 * sizeof(uint32_t));
+  w.cand_cnt = (uint32_t*)take((size_t)kQueriesPerBlock * grid * 4 * sizeof(uint32_t));
   w.scratch = (uint64_t*)take((size_t)grid * 4 * cap * sizeof(uint64_t));
   w.dense = (float*)take((size_t)kQueriesPerBlock * kSampleRows * sizeof(float));
-  w.cand = (uint64_t*)take((size_t)kQueriesPerBlock * grid * 2 * cap * sizeof(uint64_t));
+  w.cand = (uint64_t*)take((size_t)kQueriesPerBlock * grid * 4 * cap * sizeof(uint64_t));
   w.total = off;
   return w;
 }
@@ -171,7 +171,7 @@ int rr_flat_search(const void* xb, int dtype, int64_t n_rows, int dim, const voi
     memset(&s, 0, sizeof(s));
     s.thr = w.thr; s.list = w.list; s.list_cnt = w.list_cnt; s.cand = w.cand; s.cand_cnt = w.cand_cnt;
     s.dense = w.dense; s.dense_ld = kSampleRows; s.n_rows = (uint32_t)n_rows; s.nq = (uint32_t)nqb;
-    s.nbuf = (uint32_t)grid * 2; s.list_ld = kMaxK; s.cap = cap; s.k = k;
+    s.nbuf = (uint32_t)grid * (uint32_t)scan_bufs_per_wg(dim); s.list_ld = kMaxK; s.cap = cap; s.k = k;
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     a.xb = xb; a.xq = xq_b; a.thr = w.thr; a.cand = w.cand; a.cand_cnt = w.cand_cnt; a.scratch = w.scratch;

@@ -287,6 +287,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_kernel(const ScanArgs a) {
   // ordinals past the end re-load the last tile, which keeps the vmcnt bookkeeping uniform)
   auto tile_src = [&](uint32_t j) -> const char* {
     if (j >= a.n_tiles) j = a.n_tiles - 1;
+    if (VARIANT == 8) j &= 1023;  // ablation: same DMA instructions, L2/MALL-resident source (48 MB)
     const uint32_t tile = a.tile_first + j * a.tile_stride;
     uint32_t row = tile * kTileRows + wave * 8 + rho_w;
     row = row < a.n_rows ? row : a.n_rows - 1;
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_kernel(const ScanArgs a) {
     // tile j landed (this wave's pieces): all but the KG youngest DMA ops are done
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KG) : "memory");
     if (VARIANT == 2) { tB = stamp(); seg0 += tB - tA; tA = tB; }
-    __builtin_amdgcn_s_barrier();
+    if (VARIANT != 7) __builtin_amdgcn_s_barrier();
     if (VARIANT == 2) { tB = stamp(); seg1 += tB - tA; tA = tB; }
     int nslot = slot + 2;
     if (nslot >= 3) nslot -= 3;
@@ -347,6 +348,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_kernel(const ScanArgs a) {
       constexpr int NB = KS < 8 ? KS : 8;
       frag c[NB];
       uint32_t ab[4];
+      f32x4 gacc[4] = {{0}, {0}, {0}, {0}};  // VARIANT 9 only
 #pragma unroll
       for (int i = 0; i < 4; ++i) ab[i] = (uint32_t)(slot * TILE_BYTES) + roff[i];
 #pragma unroll
@@ -362,7 +364,17 @@ __global__ __launch_bounds__(256, 1) void flat_scan_kernel(const ScanArgs a) {
         else if (KS - s == 3) lgkm_wait<2>();
         else if (KS - s == 2) lgkm_wait<1>();
         else lgkm_wait<0>();
-        if (s == 0) {  // srcC = inline 0: no accumulator zero-fill
+        if (VARIANT == 9) {  // ablation: same operands and flops as 2 x 32x32x16, issued as 4 x 16x16x32 (timing only)
+          asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(gacc[0]) : "v"(c[s % NB]), "a"(q0[s]));
+          asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(gacc[1]) : "v"(c[s % NB]), "a"(q0[s]));
+          if (s < NA1) {
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(gacc[2]) : "v"(c[s % NB]), "a"(q1[s]));
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(gacc[3]) : "v"(c[s % NB]), "a"(q1[s]));
+          } else {
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(gacc[2]) : "v"(c[s % NB]), "v"(q1[s]));
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(gacc[3]) : "v"(c[s % NB]), "v"(q1[s]));
+          }
+        } else if (s == 0) {  // srcC = inline 0: no accumulator zero-fill
           MfmaAsm<T>::first_a(a0, c[0], q0[0]);
           MfmaAsm<T>::first_a(a1, c[0], q1[0]);
         } else {
@@ -370,14 +382,16 @@ __global__ __launch_bounds__(256, 1) void flat_scan_kernel(const ScanArgs a) {
           if (s < NA1) MfmaAsm<T>::acc_a(a1, c[s % NB], q1[s]);
           else MfmaAsm<T>::acc_v(a1, c[s % NB], q1[s]);
         }
-        if (s + NB < KS) lds_read_frag(c[s % NB], ab[(s + NB) & 3], ((s + NB) >> 2) * 4096);
-        if ((s & 3) == 1) issue_piece(gn, nslot, s >> 2);
+        if (s + NB < KS && VARIANT != 6) lds_read_frag(c[s % NB], ab[(s + NB) & 3], ((s + NB) >> 2) * 4096);
+        if ((s & 3) == 1 && VARIANT != 4) issue_piece(gn, nslot, s >> 2);
       }
+      if (VARIANT == 9) { asm volatile("" ::"v"(gacc[0]), "v"(gacc[1]), "v"(gacc[2]), "v"(gacc[3])); a0 = f32x16{0}; a1 = f32x16{0}; }
       mfma_drain(a0, a1);
     }
     if (VARIANT == 2) { tB = stamp(); seg2 += tB - tA; tA = tB; }
 
-    tile_epilogue<DENSE>(a, st, a0, a1, j, q0i, q1i, h, lane, wave);
+    if (VARIANT != 5 && VARIANT != 9) tile_epilogue<DENSE>(a, st, a0, a1, j, q0i, q1i, h, lane, wave);
+    else asm volatile("" ::"v"(a0), "v"(a1));
     slot = slot + 1;
     if (slot >= 3) slot = 0;
     if (VARIANT == 2) { tB = stamp(); seg3 += tB - tA; }
@@ -392,6 +406,239 @@ __global__ __launch_bounds__(256, 1) void flat_scan_kernel(const ScanArgs a) {
   if (!DENSE) {
     a.cand_cnt[q0i * nbuf + blockIdx.x * 2 + h] = st.cnt0;
     a.cand_cnt[q1i * nbuf + blockIdx.x * 2 + h] = st.cnt1;
+  }
+}
+
+// =====================================================================================================
+// 16x16x32 MFMA shape.  Same design, registers and LDS image as flat_scan_kernel; the chip holds a higher clock on
+// this shape under the combined HBM + MFMA load (measured: -6.7 % time at equal flops and operands), which is what
+// bounds the kernel.  Per wave: 4 query blocks of 16 (B operand) x 2 row blocks of 16 (A operand); D fragment:
+// column = lane&15 -> query, rows 4*(lane>>4) + reg.  A lane therefore owns 4 queries x 8 rows per tile, and the
+// candidate buffers are per (workgroup, query, lane quarter): 4 per workgroup and query.
+template <typename T> struct Mfma16Asm;
+#define RR_MFMA16(NAME, MNEMONIC, FRAG)                                                                        \
+  template <> struct Mfma16Asm<NAME> {                                                                          \
+    static __device__ __forceinline__ void first_a(f32x4& c, FRAG a, FRAG b) {                                  \
+      asm volatile(MNEMONIC " %0, %1, %2, 0" : "=v"(c) : "v"(a), "a"(b));                                      \
+    }                                                                                                           \
+    static __device__ __forceinline__ void first_v(f32x4& c, FRAG a, FRAG b) {                                  \
+      asm volatile(MNEMONIC " %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));                                      \
+    }                                                                                                           \
+    static __device__ __forceinline__ void acc_a(f32x4& c, FRAG a, FRAG b) {                                    \
+      asm volatile(MNEMONIC " %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));                                     \
+    }                                                                                                           \
+    static __device__ __forceinline__ void acc_v(f32x4& c, FRAG a, FRAG b) {                                    \
+      asm volatile(MNEMONIC " %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));                                     \
+    }                                                                                                           \
+  };
+RR_MFMA16(_Float16, "v_mfma_f32_16x16x32_f16", f16x8)
+RR_MFMA16(__bf16, "v_mfma_f32_16x16x32_bf16", bf16x8)
+#undef RR_MFMA16
+
+struct LaneState4 {
+  float thr[4];
+  uint32_t cnt[4], off[4];
+};
+
+__device__ __forceinline__ float max4v(const f32x4& v) { return max4(v[0], v[1], v[2], v[3]); }
+
+template <bool DENSE>
+__device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& st, f32x4 (&acc)[2][4], uint32_t j, int lane, int wave) {
+  const int col = lane & 15, g = lane >> 4;
+  const uint32_t tile = a.tile_first + j * a.tile_stride;
+  if (DENSE) {
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      float* d = a.dense + (size_t)(wave * 64 + qb * 16 + col) * a.dense_ld + j * kTileRows + 4 * g;
+      *(f32x4*)d = acc[0][qb];
+      *(f32x4*)(d + 16) = acc[1][qb];
+    }
+    return;
+  }
+  float gm[2][4];
+  bool hit = false;
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) {
+    gm[0][qb] = max4v(acc[0][qb]);
+    gm[1][qb] = max4v(acc[1][qb]);
+    hit = hit || (gm[0][qb] > st.thr[qb]) || (gm[1][qb] > st.thr[qb]);
+  }
+  if (!__builtin_amdgcn_ballot_w64(hit)) return;
+  // rare: typically ONE lane with ONE score; only the 4-row group that holds it is expanded
+  const uint32_t row0 = tile * kTileRows + 4 * g;
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      if (__builtin_amdgcn_ballot_w64(gm[rb][qb] > st.thr[qb])) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t id = row0 + rb * 16 + i;
+          if (acc[rb][qb][i] > st.thr[qb] && id < a.n_rows) {
+            a.cand[(size_t)st.off[qb] + st.cnt[qb]] = make_key(acc[rb][qb][i], id);
+            ++st.cnt[qb];
+          }
+        }
+      }
+    }
+  }
+  const uint32_t lim = (uint32_t)a.cap - 16u;
+  if (__builtin_amdgcn_ballot_w64(st.cnt[0] > lim || st.cnt[1] > lim || st.cnt[2] > lim || st.cnt[3] > lim)) {
+    uint64_t* scratch = a.scratch + (size_t)(blockIdx.x * 4 + wave) * a.cap;
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      uint64_t mask = __builtin_amdgcn_ballot_w64(st.cnt[qb] > lim);
+      while (mask) {
+        const int L = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const uint32_t off = __shfl(st.off[qb], L, 64);
+        const int cnt = (int)__shfl(st.cnt[qb], L, 64);
+        const uint64_t kth = wave_compact(a.cand + (size_t)__builtin_amdgcn_readfirstlane(off), scratch,
+                                          __builtin_amdgcn_readfirstlane(cnt), a.k, lane);
+        if (lane == L) { st.cnt[qb] = a.k; st.thr[qb] = key_score(kth); }
+      }
+    }
+  }
+}
+
+template <typename T, int D, bool DENSE>
+__global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
+  typedef typename Mfma<T>::frag frag;
+  constexpr int KS2 = D / 32;        // 32-wide k slices
+  constexpr int KG = D / 64;         // 64-wide k groups (DMA pieces)
+  constexpr int NF = 2 * KS2;        // corpus fragments per tile (2 row blocks per slice)
+  constexpr int NQ = 4 * KS2;        // resident query fragments per wave
+  constexpr int NAQ = NQ < 62 ? NQ : 62;  // ... of which live in AGPRs (4*62 = 248)
+  constexpr int TILE_BYTES = kTileRows * D * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 15, g = lane >> 4;
+
+  // ---- resident queries: B fragment (qb, s2): query wave*64 + qb*16 + col, k = 32 s2 + 8 g .. +7 -------------
+  frag q[4][KS2];
+  {
+    const T* xq = (const T*)a.xq;
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      const uint32_t qi = wave * 64 + qb * 16 + col;
+      const T* p = xq + (size_t)(qi < a.nq ? qi : a.nq - 1) * D + 8 * g;
+#pragma unroll
+      for (int s2 = 0; s2 < KS2; ++s2) {
+        if (qb * KS2 + s2 < NAQ) agpr_load_frag(q[qb][s2], p + 32 * s2);
+        else q[qb][s2] = *(const frag*)(p + 32 * s2);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NAQ; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+a"(q[i / KS2][i % KS2]));
+  }
+
+  LaneState4 st;
+  const uint32_t nbuf = gridDim.x * 4;
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) {
+    const uint32_t qi = wave * 64 + qb * 16 + col;
+    st.thr[qb] = DENSE ? 0.f : a.thr[qi];
+    st.cnt[qb] = 0;
+    st.off[qb] = (qi * nbuf + blockIdx.x * 4 + g) * (uint32_t)a.cap;
+  }
+
+  // ---- LDS image (identical to flat_scan_kernel's).  A fragment (rb, s2): row rb*16 + col, chunk 4*(s2&1) + g of
+  // k group s2>>1 -------------------------------------------------------------------------------------------------
+  uint32_t roff[2][2];
+  {
+    const int rho = col & 7;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int p = 2 * rb + (col >> 3);
+      const int f = ((rho >> 1) & 3) | ((p & 1) << 2);
+#pragma unroll
+      for (int par = 0; par < 2; ++par) roff[rb][par] = p * 1024 + rho * 128 + (((4 * par + g) ^ f) * 16);
+    }
+  }
+  const int rho_w = lane >> 3, sig = lane & 7;
+  const int f_w = ((rho_w >> 1) & 3) | ((wave & 1) << 2);
+  const int c_w = sig ^ f_w;
+  auto tile_src = [&](uint32_t j) -> const char* {
+    if (j >= a.n_tiles) j = a.n_tiles - 1;
+    const uint32_t tile = a.tile_first + j * a.tile_stride;
+    uint32_t row = tile * kTileRows + wave * 8 + rho_w;
+    row = row < a.n_rows ? row : a.n_rows - 1;
+    return (const char*)a.xb + (size_t)row * (D * 2) + c_w * 16;
+  };
+  auto issue_piece = [&](const char* gp, int slot, int kg) {
+    char* l = smem + slot * TILE_BYTES + wave * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + kg * 128),
+                                     (__attribute__((address_space(3))) void*)(l + kg * 4096), 16, 0, 0);
+  };
+
+  uint32_t j = blockIdx.x;
+  const uint32_t stride = gridDim.x;
+  const uint32_t n_tiles = a.n_tiles;
+  if (j < n_tiles) {
+    const char* g0 = tile_src(j);
+    const char* g1 = tile_src(j + stride);
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) issue_piece(g0, 0, kg);
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) issue_piece(g1, 1, kg);
+  }
+  int slot = 0;
+  for (; j < n_tiles; j += stride) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KG) : "memory");
+    __builtin_amdgcn_s_barrier();
+    int nslot = slot + 2;
+    if (nslot >= 3) nslot -= 3;
+    const char* gn = tile_src(j + 2 * stride);
+
+    f32x4 acc[2][4];
+    constexpr int NB = NF < 8 ? NF : 8;
+    frag c[NB];
+    uint32_t ab[2][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int par = 0; par < 2; ++par) ab[rb][par] = (uint32_t)(slot * TILE_BYTES) + roff[rb][par];
+    // fragment index f = 2*s2 + rb
+#pragma unroll
+    for (int f = 0; f < NB; ++f) lds_read_frag(c[f], ab[f & 1][(f >> 1) & 1], (f >> 2) * 4096);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int s2 = f >> 1, rb = f & 1;
+      if (NF - f >= NB) lgkm_wait<NB - 1>();
+      else if (NF - f == 7) lgkm_wait<6>();
+      else if (NF - f == 6) lgkm_wait<5>();
+      else if (NF - f == 5) lgkm_wait<4>();
+      else if (NF - f == 4) lgkm_wait<3>();
+      else if (NF - f == 3) lgkm_wait<2>();
+      else if (NF - f == 2) lgkm_wait<1>();
+      else lgkm_wait<0>();
+#pragma unroll
+      for (int qb = 0; qb < 4; ++qb) {
+        const bool in_a = qb * KS2 + s2 < NAQ;
+        if (s2 == 0) {
+          if (in_a) Mfma16Asm<T>::first_a(acc[rb][qb], c[f % NB], q[qb][0]);
+          else Mfma16Asm<T>::first_v(acc[rb][qb], c[f % NB], q[qb][0]);
+        } else {
+          if (in_a) Mfma16Asm<T>::acc_a(acc[rb][qb], c[f % NB], q[qb][s2]);
+          else Mfma16Asm<T>::acc_v(acc[rb][qb], c[f % NB], q[qb][s2]);
+        }
+      }
+      if (f + NB < NF) lds_read_frag(c[f % NB], ab[(f + NB) & 1][((f + NB) >> 1) & 1], ((f + NB) >> 2) * 4096);
+      if ((f & 3) == 1) issue_piece(gn, nslot, f >> 2);
+    }
+    asm volatile("s_nop 15\n\ts_nop 7"
+                 : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),
+                   "+v"(acc[1][2]), "+v"(acc[1][3]));
+    tile_epilogue16<DENSE>(a, st, acc, j, lane, wave);
+    slot = slot + 1;
+    if (slot >= 3) slot = 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+  if (!DENSE) {
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) a.cand_cnt[(wave * 64 + qb * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
   }
 }
 
@@ -494,7 +741,24 @@ static hipError_t launch_scan_generic(const ScanArgs& a, int D, bool dense, int 
   return hipGetLastError();
 }
 
-int g_scan_variant = 1;  // 0 = compiler-scheduled builtin MFMA, 1 = pipelined inline-asm MFMA (default)
+template <typename T> constexpr bool dtype_is_f16() { return false; }
+template <> constexpr bool dtype_is_f16<_Float16>() { return true; }
+int g_scan_variant = 16;  // 16 = 16x16x32 pipelined asm (default), 1 = 32x32x16 pipelined asm, 0 = compiler-scheduled, 3 = generic
+
+static void read_variant_env() {
+  static const bool env_read = [] {
+    if (const char* v = getenv("RR_SCAN_VARIANT")) g_scan_variant = atoi(v);
+    return true;
+  }();
+  (void)env_read;
+}
+
+// candidate buffers per (workgroup, query) of the kernel that will serve this dim
+int scan_bufs_per_wg(int D) {
+  read_variant_env();
+  return (D <= kMaxResidentDim && g_scan_variant == 16) ? 4 : 2;
+}
+
 
 template <typename T, int D, bool DENSE, int VARIANT>
 static hipError_t launch_scan_v(const ScanArgs& a, int grid, hipStream_t st) {
@@ -506,11 +770,31 @@ static hipError_t launch_scan_v(const ScanArgs& a, int grid, hipStream_t st) {
   return hipGetLastError();
 }
 
+template <typename T, int D, bool DENSE>
+static hipError_t launch_scan16(const ScanArgs& a, int grid, hipStream_t st) {
+  const size_t lds = 3 * (size_t)kTileRows * D * 2;
+  hipError_t e = hipFuncSetAttribute((const void*)flat_scan16_kernel<T, D, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((flat_scan16_kernel<T, D, DENSE>), dim3(grid), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
 template <typename T, int D>
 static hipError_t launch_scan_t(const ScanArgs& a, bool dense, int grid, hipStream_t st) {
+  if (g_scan_variant == 16) return dense ? launch_scan16<T, D, true>(a, grid, st) : launch_scan16<T, D, false>(a, grid, st);
   if (g_scan_variant == 0)
     return dense ? launch_scan_v<T, D, true, 0>(a, grid, st) : launch_scan_v<T, D, false, 0>(a, grid, st);
   if (g_scan_variant == 2 && D == 768 && !dense) return launch_scan_v<T, 768, false, 2>(a, grid, st);
+#ifdef RR_ABLATION_VARIANTS
+  if (D == 768 && !dense) {
+    if (g_scan_variant == 4) return launch_scan_v<T, 768, false, 4>(a, grid, st);
+    if (g_scan_variant == 5) return launch_scan_v<T, 768, false, 5>(a, grid, st);
+    if (g_scan_variant == 6) return launch_scan_v<T, 768, false, 6>(a, grid, st);
+    if (g_scan_variant == 7) return launch_scan_v<T, 768, false, 7>(a, grid, st);
+    if (g_scan_variant == 8) return launch_scan_v<T, 768, false, 8>(a, grid, st);
+    if (g_scan_variant == 9 && dtype_is_f16<T>()) return launch_scan_v<T, 768, false, 9>(a, grid, st);
+  }
+#endif
   return dense ? launch_scan_v<T, D, true, 1>(a, grid, st) : launch_scan_v<T, D, false, 1>(a, grid, st);
 }
 
@@ -528,11 +812,7 @@ static hipError_t launch_scan_d(const ScanArgs& a, int D, bool dense, int grid, 
 }
 
 hipError_t launch_flat_scan(const ScanArgs& a, int dtype, int D, bool dense, int grid, hipStream_t st) {
-  static const bool env_read = [] {
-    if (const char* v = getenv("RR_SCAN_VARIANT")) g_scan_variant = atoi(v);
-    return true;
-  }();
-  (void)env_read;
+  read_variant_env();
   if (D > kMaxResidentDim || g_scan_variant == 3) {  // generic-dimension kernel (also forced by RR_SCAN_VARIANT=3)
     if (D % 64 != 0) return hipErrorInvalidValue;
     if (dtype == RR_DTYPE_F16) return launch_scan_generic<_Float16>(a, D, dense, grid, st);
