@@ -159,7 +159,7 @@ def main():
                                    f"exact inner-product top-k + router MLP over {C} source(s) + cross-shard merge",
                        "rows_per_shard": n, "dim": d, "batch": B, "k": k, "parallelism": f"shard-per-gpu x{world}",
                        "unit_definition": "query x 10M-row shard searches per second, whole job (N=1: queries/sec on one shard)"},
-            "roofline": {"bound": "hbm", "kernel": "flat_scan_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "flat_scan16_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": round(alg_bytes / launches_per_step),
                          "avg_launch_ms": round(avg_launch_ms, 4), "launches_per_step": round(launches_per_step, 2),
