@@ -19,6 +19,8 @@
 //  * DENSE=true writes every score instead (bootstrap sample and tiny corpora).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "rr_common.h"
 #include "rr_kernels.h"
 
@@ -442,13 +444,13 @@ struct LaneState4 {
 
 __device__ __forceinline__ float max4v(const f32x4& v) { return max4(v[0], v[1], v[2], v[3]); }
 
-template <bool DENSE>
+template <bool DENSE, int NQB>
 __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& st, f32x4 (&acc)[2][4], uint32_t j, int lane, int wave) {
   const int col = lane & 15, g = lane >> 4;
   const uint32_t tile = a.tile_first + j * a.tile_stride;
   if (DENSE) {
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) {
+    for (int qb = 0; qb < NQB; ++qb) {
       float* d = a.dense + (size_t)(wave * 64 + qb * 16 + col) * a.dense_ld + j * kTileRows + 4 * g;
       *(f32x4*)d = acc[0][qb];
       *(f32x4*)(d + 16) = acc[1][qb];
@@ -458,7 +460,7 @@ __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& s
   float gm[2][4];
   bool hit = false;
 #pragma unroll
-  for (int qb = 0; qb < 4; ++qb) {
+  for (int qb = 0; qb < NQB; ++qb) {
     gm[0][qb] = max4v(acc[0][qb]);
     gm[1][qb] = max4v(acc[1][qb]);
     hit = hit || (gm[0][qb] > st.thr[qb]) || (gm[1][qb] > st.thr[qb]);
@@ -467,7 +469,7 @@ __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& s
   // rare: typically ONE lane with ONE score; only the 4-row group that holds it is expanded
   const uint32_t row0 = tile * kTileRows + 4 * g;
 #pragma unroll
-  for (int qb = 0; qb < 4; ++qb) {
+  for (int qb = 0; qb < NQB; ++qb) {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
       if (__builtin_amdgcn_ballot_w64(gm[rb][qb] > st.thr[qb])) {
@@ -483,10 +485,13 @@ __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& s
     }
   }
   const uint32_t lim = (uint32_t)a.cap - 16u;
-  if (__builtin_amdgcn_ballot_w64(st.cnt[0] > lim || st.cnt[1] > lim || st.cnt[2] > lim || st.cnt[3] > lim)) {
+  bool full = false;
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) full = full || st.cnt[qb] > lim;
+  if (__builtin_amdgcn_ballot_w64(full)) {
     uint64_t* scratch = a.scratch + (size_t)(blockIdx.x * 4 + wave) * a.cap;
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) {
+    for (int qb = 0; qb < NQB; ++qb) {
       uint64_t mask = __builtin_amdgcn_ballot_w64(st.cnt[qb] > lim);
       while (mask) {
         const int L = __builtin_ctzll(mask);
@@ -573,6 +578,10 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
                                      (__attribute__((address_space(3))) void*)(l + kg * 4096), 16, 0, 0);
   };
 
+  // real query blocks of this wave (wave-uniform)
+  const int nb = __builtin_amdgcn_readfirstlane(
+      (int)a.nq <= wave * 64 ? 0 : ((int)a.nq - wave * 64 >= 64 ? 4 : ((int)a.nq - wave * 64 + 15) / 16));
+
   uint32_t j = blockIdx.x;
   const uint32_t stride = gridDim.x;
   const uint32_t n_tiles = a.n_tiles;
@@ -592,46 +601,63 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
     if (nslot >= 3) nslot -= 3;
     const char* gn = tile_src(j + 2 * stride);
 
-    f32x4 acc[2][4];
-    constexpr int NB = NF < 8 ? NF : 8;
-    frag c[NB];
-    uint32_t ab[2][2];
+    // Small batches (the reference issues ONE query per search, data_source.py:114): query blocks past nq do no
+    // MFMA work.  nb = this wave's real query blocks: 4 -> full loop, 1..3 -> loop over nb... (1 or 4 compiled),
+    // 0 -> the wave only feeds the DMA ring and the barrier, so a 1-query search runs HBM-bound.
+    auto compute = [&](auto tag) {
+      constexpr int NQB = decltype(tag)::value;
+      f32x4 acc[2][4];
+      constexpr int NB = NF < 8 ? NF : 8;
+      frag c[NB];
+      uint32_t ab[2][2];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+      for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int par = 0; par < 2; ++par) ab[rb][par] = (uint32_t)(slot * TILE_BYTES) + roff[rb][par];
-    // fragment index f = 2*s2 + rb
+        for (int par = 0; par < 2; ++par) ab[rb][par] = (uint32_t)(slot * TILE_BYTES) + roff[rb][par];
+      // fragment index f = 2*s2 + rb
 #pragma unroll
-    for (int f = 0; f < NB; ++f) lds_read_frag(c[f], ab[f & 1][(f >> 1) & 1], (f >> 2) * 4096);
+      for (int f = 0; f < NB; ++f) lds_read_frag(c[f], ab[f & 1][(f >> 1) & 1], (f >> 2) * 4096);
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      const int s2 = f >> 1, rb = f & 1;
-      if (NF - f >= NB) lgkm_wait<NB - 1>();
-      else if (NF - f == 7) lgkm_wait<6>();
-      else if (NF - f == 6) lgkm_wait<5>();
-      else if (NF - f == 5) lgkm_wait<4>();
-      else if (NF - f == 4) lgkm_wait<3>();
-      else if (NF - f == 3) lgkm_wait<2>();
-      else if (NF - f == 2) lgkm_wait<1>();
-      else lgkm_wait<0>();
+      for (int f = 0; f < NF; ++f) {
+        const int s2 = f >> 1, rb = f & 1;
+        if (NF - f >= NB) lgkm_wait<NB - 1>();
+        else if (NF - f == 7) lgkm_wait<6>();
+        else if (NF - f == 6) lgkm_wait<5>();
+        else if (NF - f == 5) lgkm_wait<4>();
+        else if (NF - f == 4) lgkm_wait<3>();
+        else if (NF - f == 3) lgkm_wait<2>();
+        else if (NF - f == 2) lgkm_wait<1>();
+        else lgkm_wait<0>();
 #pragma unroll
-      for (int qb = 0; qb < 4; ++qb) {
-        const bool in_a = qb * KS2 + s2 < NAQ;
-        if (s2 == 0) {
-          if (in_a) Mfma16Asm<T>::first_a(acc[rb][qb], c[f % NB], q[qb][0]);
-          else Mfma16Asm<T>::first_v(acc[rb][qb], c[f % NB], q[qb][0]);
-        } else {
-          if (in_a) Mfma16Asm<T>::acc_a(acc[rb][qb], c[f % NB], q[qb][s2]);
-          else Mfma16Asm<T>::acc_v(acc[rb][qb], c[f % NB], q[qb][s2]);
+        for (int qb = 0; qb < NQB; ++qb) {
+          const bool in_a = qb * KS2 + s2 < NAQ;
+          if (s2 == 0) {
+            if (in_a) Mfma16Asm<T>::first_a(acc[rb][qb], c[f % NB], q[qb][0]);
+            else Mfma16Asm<T>::first_v(acc[rb][qb], c[f % NB], q[qb][0]);
+          } else {
+            if (in_a) Mfma16Asm<T>::acc_a(acc[rb][qb], c[f % NB], q[qb][s2]);
+            else Mfma16Asm<T>::acc_v(acc[rb][qb], c[f % NB], q[qb][s2]);
+          }
         }
+        if (f + NB < NF) lds_read_frag(c[f % NB], ab[(f + NB) & 1][((f + NB) >> 1) & 1], ((f + NB) >> 2) * 4096);
+        if ((f & 3) == 1) issue_piece(gn, nslot, f >> 2);
       }
-      if (f + NB < NF) lds_read_frag(c[f % NB], ab[(f + NB) & 1][((f + NB) >> 1) & 1], ((f + NB) >> 2) * 4096);
-      if ((f & 3) == 1) issue_piece(gn, nslot, f >> 2);
+      if (NQB == 4)
+        asm volatile("s_nop 15\n\ts_nop 7"
+                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),
+                       "+v"(acc[1][2]), "+v"(acc[1][3]));
+      else
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][0]));
+      tile_epilogue16<DENSE, NQB>(a, st, acc, j, lane, wave);
+    };
+    if (nb >= 2) {
+      compute(std::integral_constant<int, 4>{});
+    } else if (nb == 1) {
+      compute(std::integral_constant<int, 1>{});
+    } else {
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg) issue_piece(gn, nslot, kg);
     }
-    asm volatile("s_nop 15\n\ts_nop 7"
-                 : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),
-                   "+v"(acc[1][2]), "+v"(acc[1][3]));
-    tile_epilogue16<DENSE>(a, st, acc, j, lane, wave);
     slot = slot + 1;
     if (slot >= 3) slot = 0;
   }

@@ -30,4 +30,4 @@ def main(n=1_000_000, d=768, nq=256, k=32, iters=10):
           bool(((I[:, 0] >= 200000) | (I[:, 0] == S.argmax(1))).all()))
 
 if __name__ == "__main__":
-    main(n=int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, d=int(sys.argv[2]) if len(sys.argv) > 2 else 768)
+    main(n=int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, d=int(sys.argv[2]) if len(sys.argv) > 2 else 768, nq=int(sys.argv[3]) if len(sys.argv) > 3 else 256)

@@ -83,6 +83,17 @@ def test_generic_dimension_bit_exact(gpu, d):
     assert np.array_equal(I2, Ir2) and np.array_equal(D2, Dr2)
 
 
+@pytest.mark.parametrize("nq", [1, 16, 17, 63, 65, 129, 200])
+def test_partial_query_blocks(gpu, nq):
+    """Waves / query blocks without real queries skip their MFMA work; every batch size must stay exact."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(nq)
+    xb, xq = int_data(rng, 40_000, 768), int_data(rng, nq, 768)
+    D, I = _index(gpu, xb, 768).search(xq, 32)
+    Dref, Iref = O.flat_search_ip(xb, xq, 32)
+    assert np.array_equal(I, Iref) and np.array_equal(D, Dref)
+
+
 def test_no_queries(gpu):
     idx = _index(gpu, int_data(np.random.default_rng(0), 100, 768), 768)
     D, I = idx.search(np.zeros((0, 768), np.float32), 5)
