@@ -92,7 +92,7 @@ Workspace carve(char* base, int k, int grid) {
   w.list_cnt = (uint32_t*)take(kQueriesPerBlock * sizeof(uint32_t));
   w.list = (uint64_t*)take((size_t)kQueriesPerBlock * kMaxK * sizeof(uint64_t));
   w.cand_cnt = (uint32_t*)take((size_t)kQueriesPerBlock * grid * 4 * sizeof(uint32_t));
-  w.scratch = (uint64_t*)take((size_t)grid * 4 * cap * sizeof(uint64_t));
+  w.scratch = (uint64_t*)take((size_t)grid * 8 * cap * sizeof(uint64_t));  // up to 2 workgroups per CU x 4 waves
   w.dense = (float*)take((size_t)kQueriesPerBlock * kSampleRows * sizeof(float));
   w.cand = (uint64_t*)take((size_t)kQueriesPerBlock * grid * 4 * cap * sizeof(uint64_t));
   w.total = off;

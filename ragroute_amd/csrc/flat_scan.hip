@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
 // piece layout as the fast kernel) and is shared by the 4 waves.  Two 32-row tiles per iteration halve the L2
 // traffic of the queries.  Compiler-scheduled (builtin MFMA, __syncthreads); same epilogue, same host schedule.
 template <typename T, bool DENSE>
-__global__ __launch_bounds__(256, 1) void flat_scan_generic_kernel(const ScanArgs a, const int D) {
+__global__ __launch_bounds__(256, 2) void flat_scan_generic_kernel(const ScanArgs a, const int D) {
   typedef typename Mfma<T>::frag frag;
   __shared__ __attribute__((aligned(16))) char smem[2][2 * 4096];  // [buffer][tile A | tile B] 32 rows x 128 B each
   const int tid = threadIdx.x, lane = tid & 63;
@@ -762,8 +762,9 @@ __global__ __launch_bounds__(256, 1) void flat_scan_generic_kernel(const ScanArg
 
 template <typename T>
 static hipError_t launch_scan_generic(const ScanArgs& a, int D, bool dense, int grid, hipStream_t st) {
-  if (dense) hipLaunchKernelGGL((flat_scan_generic_kernel<T, true>), dim3(grid), dim3(256), 0, st, a, D);
-  else hipLaunchKernelGGL((flat_scan_generic_kernel<T, false>), dim3(grid), dim3(256), 0, st, a, D);
+  // two workgroups per CU (<= 256 registers per lane, 16 KB LDS): thread-level parallelism hides the L2 / barrier latency
+  if (dense) hipLaunchKernelGGL((flat_scan_generic_kernel<T, true>), dim3(2 * grid), dim3(256), 0, st, a, D);
+  else hipLaunchKernelGGL((flat_scan_generic_kernel<T, false>), dim3(2 * grid), dim3(256), 0, st, a, D);
   return hipGetLastError();
 }
 
@@ -782,7 +783,8 @@ static void read_variant_env() {
 // candidate buffers per (workgroup, query) of the kernel that will serve this dim
 int scan_bufs_per_wg(int D) {
   read_variant_env();
-  return (D <= kMaxResidentDim && g_scan_variant == 16) ? 4 : 2;
+  if (D > kMaxResidentDim || g_scan_variant == 3) return 4;  // generic kernel: 2 workgroups per CU x 2 lane halves
+  return g_scan_variant == 16 ? 4 : 2;
 }
 
 

@@ -166,3 +166,20 @@ def test_bad_arguments(gpu):
         idx.search(np.zeros((1, 768), np.float32), 5000)
     with pytest.raises(ValueError):
         idx.search(np.zeros((1, 100), np.float32), 5)
+
+
+def test_randomised_shapes(gpu):
+    """30 seeded random (n, d, nq, k, dtype) configurations on exact integer data: ids and scores bit for bit."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(20261004)
+    for it in range(30):
+        n = int(rng.choice([0, 1, 33, 700, 8192, 8193, 9000, 20_000, 66_000]) + rng.integers(0, 50))
+        d = int(rng.choice([8, 64, 100, 128, 200, 384, 600, 768, 769, 1024]))
+        nq = int(rng.choice([1, 2, 15, 16, 17, 64, 100, 256, 257]))
+        k = int(rng.choice([1, 5, 10, 32, 33, 100, 128, 200]))
+        dtype = "fp16" if rng.integers(0, 2) else "bf16"
+        xb, xq = int_data(rng, n, d, -2, 3), int_data(rng, nq, d, -2, 3)
+        D, I = _index(gpu, xb, d, dtype=dtype).search(xq, k)
+        Dref, Iref = O.flat_search_ip(xb.reshape(n, d), xq, k)
+        assert np.array_equal(I, Iref), (it, n, d, nq, k, dtype)
+        assert np.array_equal(D, Dref), (it, n, d, nq, k, dtype)
