@@ -77,9 +77,7 @@ def main():
 
     from ragroute_amd._lib import check, lib
     from ragroute_amd.flat_index import FlatIndex
-    from ragroute_amd.rerank import merge_topk
     from ragroute_amd.router import CorpusRoutingNN, FoldedRouter
-    from ragroute_amd.sharded import SHARD_SHIFT, apply_route_mask, gather_candidates
 
     d, B, k, n = args.dim, args.batch, args.k, args.rows
     tdt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
@@ -106,12 +104,11 @@ def main():
     router = FoldedRouter.fold(net.state_dict(), cen_all, list(range(C)), C, d, [0] * C, 0.5, device=dev)
     xq_router = xq[:, None, :].contiguous()
 
-    def step():
-        _, mask = router.run(xq_router)                                    # K3
-        xqh = idx.prepare_queries(xq)                                      # K0 (f32 -> fp16 rows)
-        D, I = idx.search_prepared(xqh, k, id_offset=rank << SHARD_SHIFT, route_mask=mask[:, rank])  # K1/K2 + route mask
-        Dg, Ig = gather_candidates(D, I)                                   # RCCL all_gather (N > 1)
-        return merge_topk(Dg, Ig, k, True)                                 # K4
+    from ragroute_amd.pipeline import RetrievalPipeline
+    pipe = RetrievalPipeline([idx], [rank], router=router)
+
+    def step():  # K3 router -> K0 convert -> K1/K2 scan+top-k (route mask folded in) -> all_gather (N>1) -> K4 merge
+        return pipe.search(xq, k, xq_models=xq_router)
 
     def fence():
         torch.cuda.synchronize()

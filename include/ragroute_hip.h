@@ -54,6 +54,12 @@ int rr_l2_normalize_f32(float* d_x, int64_t n, int64_t d, void* stream);
 int rr_rows_to_half(const float* d_x, int64_t n, int64_t d, int64_t ld_in, void* d_out, int dtype,
                     int64_t d_out_dim, int normalize, void* stream);
 
+/* Column means of an HBM-resident corpus: the per-source "centroid" feature of the router.  The reference only
+ * CONSUMES it (`corpus_stats["centroid"]`, ragroute/router.py:147-151; the *_stats.json files are produced
+ * off-tree); this builds it for synthetic or new corpora.  d_xb as for rr_flat_search; d_out device f32 [dim]
+ * (entries >= d are zero, matching the zero padding of router.py:150). */
+int rr_centroid(const void* d_xb, int dtype, int64_t n_rows, int dim, int d, float* d_out, void* stream);
+
 /* Bytes of device workspace rr_flat_search needs for this k on the current device. */
 size_t rr_flat_search_workspace_bytes(int k);
 

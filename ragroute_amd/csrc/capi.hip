@@ -130,6 +130,14 @@ int rr_rows_to_half(const float* x, int64_t n, int64_t d, int64_t ld_in, void* o
   return e == hipSuccess ? RR_OK : hip_fail(e, "rr_rows_to_half");
 }
 
+int rr_centroid(const void* xb, int dtype, int64_t n_rows, int dim, int d, float* out, void* stream) {
+  if (n_rows < 0 || d < 1 || d > dim || dim % 64 != 0 || !out || (!xb && n_rows > 0))
+    return fail(RR_ERR_INVALID, "rr_centroid: bad arguments%s");
+  if (dtype != RR_DTYPE_F16 && dtype != RR_DTYPE_BF16) return fail(RR_ERR_INVALID, "rr_centroid: bad dtype%s");
+  hipError_t e = rr::launch_centroid(xb, dtype, n_rows, dim, d, out, (hipStream_t)stream);
+  return e == hipSuccess ? RR_OK : hip_fail(e, "rr_centroid");
+}
+
 size_t rr_flat_search_workspace_bytes(int k) {
   if (k < 1 || k > rr::kMaxK) return 0;
   int grid = device_cus();

@@ -58,6 +58,50 @@ __global__ __launch_bounds__(256) void rows_to_half_kernel(const float* x, int64
   }
 }
 
+// Column means of an HBM-resident corpus (the "centroid" the router consumes, reference router.py:147-151; the
+// reference reads it from *_stats.json produced off-tree).  Each thread owns 8 consecutive columns (16-byte loads),
+// a workgroup strides over rows, partial sums meet with float atomics (<= 2048 adds per column).
+template <typename T>
+__global__ __launch_bounds__(256) void column_sum_kernel(const T* __restrict__ xb, int64_t n, int dim, float* __restrict__ sums) {
+  typedef T vec8 __attribute__((ext_vector_type(8)));
+  const int cols8 = dim / 8;                       // dim is a multiple of 64
+  const int tpr = cols8 < 256 ? cols8 : 256;       // threads that cover one row pass
+  const int rows_per_pass = 256 / tpr > 0 ? 256 / tpr : 1;
+  const int t = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+  for (int c8 = t; c8 < cols8; c8 += tpr) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (rsub < rows_per_pass) {
+      for (int64_t r = (int64_t)blockIdx.x * rows_per_pass + rsub; r < n; r += (int64_t)gridDim.x * rows_per_pass) {
+        const vec8 v = *(const vec8*)(xb + r * dim + c8 * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += (float)v[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) atomicAdd(&sums[c8 * 8 + i], acc[i]);
+    }
+  }
+}
+
+__global__ void scale_kernel(float* x, int d, float s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < d) x[i] *= s;
+}
+
+hipError_t launch_centroid(const void* xb, int dtype, int64_t n, int dim, int d, float* out, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)dim * sizeof(float), st);
+  if (e != hipSuccess) return e;
+  if (n == 0) return hipSuccess;
+  int64_t g = (n + 63) / 64;
+  if (g > 2048) g = 2048;
+  if (dtype == RR_DTYPE_F16) hipLaunchKernelGGL(column_sum_kernel<_Float16>, dim3((int)g), dim3(256), 0, st, (const _Float16*)xb, n, dim, out);
+  else if (dtype == RR_DTYPE_BF16) hipLaunchKernelGGL(column_sum_kernel<__bf16>, dim3((int)g), dim3(256), 0, st, (const __bf16*)xb, n, dim, out);
+  else return hipErrorInvalidValue;
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(scale_kernel, dim3((d + 255) / 256), dim3(256), 0, st, out, d, 1.0f / (float)n);
+  return hipGetLastError();
+}
+
 static int grid_for_rows(int64_t n) {
   int64_t g = (n + 3) / 4;
   if (g > 8192) g = 8192;

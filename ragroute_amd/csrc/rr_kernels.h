@@ -50,6 +50,8 @@ hipError_t launch_l2_normalize_f32(float* x, int64_t n, int64_t d, hipStream_t s
 hipError_t launch_rows_to_half(const float* x, int64_t n, int64_t d, int64_t ld_in, void* out, int dtype, int64_t d_out,
                                int normalize, hipStream_t st);
 
+hipError_t launch_centroid(const void* xb, int dtype, int64_t n, int dim, int d, float* out, hipStream_t st);
+
 // router.hip
 hipError_t launch_router_mlp(const rr_router_weights* w, const float* xq, int nq, float* logits, uint8_t* mask,
                              hipStream_t st);

@@ -101,6 +101,14 @@ class FlatIndex:
         self._xb = xb_dev
         self.ntotal = int(xb_dev.shape[0] if ntotal is None else ntotal)
 
+    def centroid(self):
+        """float32 CUDA vector [d]: mean of the stored rows (the router's centroid feature, router.py:147-151)."""
+        out = torch.empty(self.dim, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().rr_centroid(self._xb.data_ptr(), _RR_DTYPE[self.dtype], self.ntotal, self.dim, self.d, out.data_ptr(),
+                                    _stream_ptr()), "rr_centroid")
+        return out[: self.d]
+
     @property
     def xb(self):
         return self._xb[: self.ntotal]

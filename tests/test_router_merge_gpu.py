@@ -186,3 +186,49 @@ def test_batched_serving_equals_per_query_replies(gpu):
         assert rep["query_id"] == f"q{i}" and rep["client_id"] == 0 and rep["name"] == "textbooks"
         assert rep["indices"] == ids and rep["docs"] == docs and rep["scores"] == scores
         json.dumps(rep)  # wire format must be JSON-serialisable
+
+
+def test_centroid_kernel(gpu):
+    from ragroute_amd.flat_index import FlatIndex
+    rng = np.random.default_rng(3)
+    for n, d, dtype in [(5000, 768, "fp16"), (777, 100, "bf16"), (3000, 1024, "fp16"), (1, 64, "fp16")]:
+        x = half_round(rng.standard_normal((n, d)).astype(np.float32), dtype)
+        idx = FlatIndex(d, dtype=dtype, device=gpu)
+        idx.add(x)
+        got = idx.centroid().cpu().numpy()
+        assert got.shape == (d,)
+        assert np.allclose(got, x.astype(np.float64).mean(0), atol=2e-5)
+
+
+def test_pipeline_route_search_merge(gpu):
+    """Whole hot path on device (router -> masked shard scans -> merge) == oracle over the shards each query was routed to."""
+    from oracle import oracle as O
+    from ragroute_amd import config as C
+    from ragroute_amd.flat_index import FlatIndex
+    from ragroute_amd.pipeline import RetrievalPipeline
+    from ragroute_amd.sharded import SHARD_SHIFT
+    r, case = _router("medrag", 11)
+    rng = np.random.default_rng(4)
+    parts = [int_data(rng, n, 768) for n in (9000, 20_000, 700, 12_345)]
+    shards = []
+    for p in parts:
+        idx = FlatIndex(768, device=gpu)
+        idx.add(p)
+        shards.append(idx)
+    xq = int_data(rng, 24, 768)
+    pipe = RetrievalPipeline(shards, [0, 1, 2, 3], router=r._folded)
+    xt = torch.from_numpy(xq).to(gpu)
+    D, I = pipe.search(xt, 32)
+    _, mask = pipe.route(xt[:, None, :].contiguous())
+    mask = mask.cpu().numpy()
+    assert mask.any() and not mask.all()
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    for q in range(24):
+        sel = [s for s in range(4) if mask[q, s]]
+        if not sel:
+            assert (I[q] == -1).all()
+            continue
+        cat = np.concatenate([parts[s] for s in sel])
+        gids = np.concatenate([np.arange(len(parts[s])) + (s << SHARD_SHIFT) for s in sel])
+        Dr, Ir = O.flat_search_ip(cat, xq[q:q + 1], 32)
+        assert np.array_equal(D[q], Dr[0]) and np.array_equal(I[q], gids[Ir[0]])

@@ -1,5 +1,7 @@
 """Quick device timing of the flat search (development aid; bench.py is the contract)."""
-import sys, time
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import time
 import torch
 from ragroute_amd.flat_index import FlatIndex
 

@@ -1,5 +1,6 @@
 """Diagnostic (RR_SCAN_VARIANT=2): share of the scan loop's cycles per segment, from in-kernel s_memtime stamps."""
-import os
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["RR_SCAN_VARIANT"] = "2"
 import torch
 from ragroute_amd.flat_index import FlatIndex
