@@ -219,7 +219,7 @@ class Router:
                 stats = stats[int(corpus)]
             centroid = np.array(stats["centroid"], dtype=np.float32)
             self.centroids[corpus] = np.pad(centroid, (0, config.EMBEDDING_MAX_LENGTH[ds] - len(centroid)))
-        self._fold()
+        self._folded = None  # folded onto the device lazily, at the first routing call
 
     def set_router(self, state_dict, centroids: Dict[str, np.ndarray], scaler_mean=None, scaler_scale=None):
         """Install weights directly (synthetic corpora, tests): same objects load_router() would build."""
@@ -229,7 +229,7 @@ class Router:
         d_max = config.EMBEDDING_MAX_LENGTH[ds]
         self.centroids = {c: np.pad(np.asarray(v, np.float32), (0, d_max - len(v))) for c, v in centroids.items()}
         self.scaler = None if scaler_mean is None else _ScalerLike(scaler_mean, scaler_scale)
-        self._fold()
+        self._folded = None
 
     def _fold(self):
         ds = self.dataset
@@ -275,7 +275,9 @@ class Router:
     def route_batch(self, xq):
         """xq: tensor [B, n_models, d_max] (host or device) -> (logits [B,C], mask bool [B,C]) device tensors."""
         if self._folded is None:
-            raise RuntimeError("router weights not loaded: call load_router() or set_router() first")
+            if self.router is None:
+                raise RuntimeError("router weights not loaded: call load_router() or set_router() first")
+            self._fold()
         return self._folded.run(xq if isinstance(xq, torch.Tensor) else torch.as_tensor(xq))
 
     def select_relevant_sources_ragroute(self, query_embeddings: Dict[str, np.ndarray]) -> List[str]:

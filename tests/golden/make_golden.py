@@ -144,6 +144,25 @@ def golden_data_source_glue():
             indices, docs, scores = ds.retrieve_docs_medrag(q.reshape(1, -1), 32)
             res.append({"indices": indices, "docs": docs, "scores": [float(s) for s in scores]})
         out["medrag"] = {"corpus_seed": 5, "query_seed": 99, "k": 32, "results": res}
+        # feb4rag: ids are docids strings, docs come from corpus.jsonl keyed by _id, NO scores (data_source.py:143-163)
+        DS.FEB4RAG_DIR = RC.FEB4RAG_DIR = tmp
+        fs = DS.DataSource(1, "feb4rag", "scifact")
+        os.makedirs(fs.index_dir)
+        docids = [f"doc-{i * 7 % 1000}-{i}" for i in range(xb.shape[0])]
+        json.dump(docids, open(fs.doc_ids_path, "w"))
+        cdir = os.path.join(tmp, "dataset_creation/original_dataset", "scifact", "scifact")
+        os.makedirs(cdir)
+        with open(os.path.join(cdir, "corpus.jsonl"), "w") as f:
+            for i, did in enumerate(docids):
+                if i % 5 != 0:  # some docids are missing from the corpus file -> None entries
+                    f.write(json.dumps({"_id": did, "title": f"t{i}", "text": f"body {i}"}) + "\n")
+        store[fs.index_path] = xb
+        fs.load_faiss_index()
+        res = []
+        for q in queries:
+            ids, docs, scores = fs.retrieve_docs_fed4rag(q.reshape(1, -1), 10)
+            res.append({"ids": ids, "docs": docs, "scores": scores})
+        out["feb4rag"] = {"k": 10, "results": res}
         # wikipedia: normalize_L2 on the query, ids are the rows, docs are (title, text)
         DS.WIKIPEDIA_DIR = tmp
         split = os.path.join(tmp, "faiss_clusters", "split_texts_titles")

@@ -103,3 +103,48 @@ def test_rerank_feb4rag_host_path_matches_golden():
     for c in g["cases"]:
         d, i = rerank_feb4rag(c["ids"], c["docs"], c["query_id"], c["k"], rel)
         assert d == c["out_docs"] and i == c["out_ids"]
+
+
+def test_load_router_reads_the_reference_file_formats(tmp_path):
+    """router.py:106-151: state_dict via torch.load, medrag scaler = 4th element of a 5-tuple pickle, wikipedia scaler = bare
+    pickle, centroid = stats JSON ["centroid"] zero padded to the dataset's max length (wikipedia: list indexed by cluster)."""
+    import pickle
+    import torch
+    from sklearn.preprocessing import StandardScaler
+    from ragroute_amd import config as C
+    from ragroute_amd.router import Router
+    case = synth_router_case("medrag", 31)
+    model = tmp_path / "best_model.pth"
+    torch.save({k: torch.from_numpy(v) for k, v in case["sd"].items()}, model)
+    sc = StandardScaler()
+    sc.mean_, sc.scale_ = case["scaler"]
+    sc.var_, sc.n_features_in_ = sc.scale_ ** 2, len(sc.mean_)
+    pk = tmp_path / "preprocessed_data.pkl"
+    pickle.dump(("X_train", "X_test", "y", sc, "extra"), open(pk, "wb"))
+    stats = {}
+    for c, v in case["centroids"].items():
+        f = tmp_path / f"{c}_stats.json"
+        json.dump({"centroid": v[:700].tolist(), "n": 5}, open(f, "w"))   # shorter than 768 -> must be zero padded
+        stats[c] = str(f)
+    r = Router("medrag", case["sources"], "ragroute")
+    r.load_router(model_path=str(model), scaler_path=str(pk), stats_files=stats)
+    assert np.array_equal(r.router.state_dict()["fc1.weight"], case["sd"]["fc1.weight"])
+    assert np.array_equal(r.scaler.mean_, case["scaler"][0])
+    for c in case["sources"]:
+        assert r.centroids[c].shape == (768,) and (r.centroids[c][700:] == 0).all()
+        assert np.array_equal(r.centroids[c][:700], case["centroids"][c][:700])
+    # wikipedia: bare scaler pickle and one stats file holding a list indexed by cluster id
+    wcase = synth_router_case("wikipedia", 32)
+    torch.save({k: torch.from_numpy(v) for k, v in wcase["sd"].items()}, model)
+    wsc = StandardScaler()
+    wsc.mean_, wsc.scale_ = wcase["scaler"]
+    pickle.dump(wsc, open(pk, "wb"))
+    f = tmp_path / "cluster_stats.json"
+    json.dump([{"centroid": wcase["centroids"][str(i)].tolist()} for i in range(10)], open(f, "w"))
+    w = Router("wikipedia", wcase["sources"], "ragroute")
+    w.load_router(model_path=str(model), scaler_path=str(pk), stats_files={c: str(f) for c in wcase["sources"]})
+    assert np.array_equal(w.centroids["7"], wcase["centroids"]["7"]) and np.array_equal(w.scaler.scale_, wcase["scaler"][1])
+    with pytest.raises(KeyError):
+        bad = dict(wcase["sd"])
+        del bad["ln2.bias"]
+        w.router.load_state_dict(bad)

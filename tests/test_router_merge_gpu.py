@@ -150,6 +150,23 @@ def test_data_source_glue_matches_reference_golden(gpu, tmp_path, monkeypatch):
     # batched form = per-query tuples
     allres = ds.retrieve_docs_medrag(queries, g["medrag"]["k"])
     assert [r[0] for r in allres] == [w["indices"] for w in g["medrag"]["results"]]
+    # feb4rag: docid strings, corpus.jsonl lookups (None when missing), no scores
+    monkeypatch.setattr(C, "FEB4RAG_DIR", str(tmp_path))
+    fs = DS.DataSource(1, "feb4rag", "scifact")
+    os.makedirs(fs.index_dir)
+    docids = [f"doc-{i * 7 % 1000}-{i}" for i in range(xb.shape[0])]
+    DS.write_faiss_flat_index(fs.index_path, xb)
+    json.dump(docids, open(fs.doc_ids_path, "w"))
+    cdir = tmp_path / "dataset_creation/original_dataset" / "scifact" / "scifact"
+    os.makedirs(cdir)
+    with open(cdir / "corpus.jsonl", "w") as f:
+        for i, did in enumerate(docids):
+            if i % 5 != 0:
+                f.write(json.dumps({"_id": did, "title": f"t{i}", "text": f"body {i}"}) + "\n")
+    fs.load_faiss_index()
+    for q, want in zip(queries, g["feb4rag"]["results"]):
+        ids, docs, scores = fs.retrieve_docs_fed4rag(q.reshape(1, -1), g["feb4rag"]["k"])
+        assert ids == want["ids"] and docs == want["docs"] and scores == [] == want["scores"]
     # wikipedia: normalised query, row ids, (title, text) docs
     n = xb.shape[0]
     ws = DS.DataSource(3, "wikipedia", "3")
@@ -216,6 +233,7 @@ def test_pipeline_route_search_merge(gpu):
         idx.add(p)
         shards.append(idx)
     xq = int_data(rng, 24, 768)
+    r._fold()
     pipe = RetrievalPipeline(shards, [0, 1, 2, 3], router=r._folded)
     xt = torch.from_numpy(xq).to(gpu)
     D, I = pipe.search(xt, 32)

@@ -20,7 +20,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 ws = idx._ws[k]
 grid = 256
-off = 1024 + 1024 + 256 * 1024 * 8 + 256 * grid * 2 * 4 + grid * 4 * 64 * 8
+off = 1024 + 1024 + 256 * 1024 * 8 + 256 * grid * 4 * 4 + grid * 8 * 64 * 8
 dbg = ws[off: off + grid * 4 * 6 * 8].view(torch.int64).reshape(grid, 4, 6).cpu().double()
 clk = dbg[:, :, 4] / dbg[:, :, 5] * 100e6
 print(f'in-kernel clock: median {clk.median().item()/1e9:.3f} GHz (min {clk.min().item()/1e9:.3f}, max {clk.max().item()/1e9:.3f}); loop {dbg[:,:,5].mean().item()/100:.1f} us')
