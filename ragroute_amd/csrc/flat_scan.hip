@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_kernel(const ScanArgs a) {
   // ordinals past the end re-load the last tile, which keeps the vmcnt bookkeeping uniform)
   auto tile_src = [&](uint32_t j) -> const char* {
     if (j >= a.n_tiles) j = a.n_tiles - 1;
-    if (VARIANT == 8) j &= 1023;  // ablation: same DMA instructions, L2/MALL-resident source (48 MB)
+    if (VARIANT == 48) j &= 1023;  // ablation: same DMA instructions, L2/MALL-resident source (48 MB)
     const uint32_t tile = a.tile_first + j * a.tile_stride;
     uint32_t row = tile * kTileRows + wave * 8 + rho_w;
     row = row < a.n_rows ? row : a.n_rows - 1;
@@ -444,14 +444,14 @@ struct LaneState4 {
 
 __device__ __forceinline__ float max4v(const f32x4& v) { return max4(v[0], v[1], v[2], v[3]); }
 
-template <bool DENSE, int NQB>
+template <bool DENSE, int NQB, int QPW = 64>
 __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& st, f32x4 (&acc)[2][4], uint32_t j, int lane, int wave) {
   const int col = lane & 15, g = lane >> 4;
   const uint32_t tile = a.tile_first + j * a.tile_stride;
   if (DENSE) {
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
-      float* d = a.dense + (size_t)(wave * 64 + qb * 16 + col) * a.dense_ld + j * kTileRows + 4 * g;
+      float* d = a.dense + (size_t)(wave * QPW + qb * 16 + col) * a.dense_ld + j * kTileRows + 4 * g;
       *(f32x4*)d = acc[0][qb];
       *(f32x4*)(d + 16) = acc[1][qb];
     }
@@ -489,7 +489,7 @@ __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& s
 #pragma unroll
   for (int qb = 0; qb < NQB; ++qb) full = full || st.cnt[qb] > lim;
   if (__builtin_amdgcn_ballot_w64(full)) {
-    uint64_t* scratch = a.scratch + (size_t)(blockIdx.x * 4 + wave) * a.cap;
+    uint64_t* scratch = a.scratch + (size_t)(blockIdx.x * (256 / QPW) + wave) * a.cap;
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
       uint64_t mask = __builtin_amdgcn_ballot_w64(st.cnt[qb] > lim);
@@ -506,7 +506,7 @@ __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& s
   }
 }
 
-template <typename T, int D, bool DENSE>
+template <typename T, int D, bool DENSE, bool NT = false>
 __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   typedef typename Mfma<T>::frag frag;
   constexpr int KS2 = D / 32;        // 32-wide k slices
@@ -574,8 +574,12 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   };
   auto issue_piece = [&](const char* gp, int slot, int kg) {
     char* l = smem + slot * TILE_BYTES + wave * 1024;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + kg * 128),
-                                     (__attribute__((address_space(3))) void*)(l + kg * 4096), 16, 0, 0);
+    if (NT)  // non-temporal: the corpus is read once per batch, keep it out of L2 / Infinity Cache
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + kg * 128),
+                                       (__attribute__((address_space(3))) void*)(l + kg * 4096), 16, 0, 2);
+    else
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + kg * 128),
+                                       (__attribute__((address_space(3))) void*)(l + kg * 4096), 16, 0, 0);
   };
 
   // real query blocks of this wave (wave-uniform)
@@ -665,6 +669,156 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   if (!DENSE) {
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) a.cand_cnt[(wave * 64 + qb * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
+  }
+}
+
+// ---- 8-wave form: two waves per SIMD, 32 resident queries per wave ---------------------------------------------
+// One wave per SIMD cannot hide its own in-order stalls: every LDS-DMA issue holds the wave ~50 cycles past the MFMA's
+// free issue slots, and the epilogue and the first fragment reads of a tile leave the matrix pipe idle.  With two
+// waves per SIMD the partner's MFMAs fill those holes.  Cost: 256 registers per lane (192 query + 16 accumulator +
+// 16 fragment ring + ~30), and every tile is read from LDS by 8 waves instead of 4.
+template <typename T, int D, bool DENSE>
+__global__ __launch_bounds__(512, 2) void flat_scan16x8_kernel(const ScanArgs a) {
+  typedef typename Mfma<T>::frag frag;
+  constexpr int KS2 = D / 32, KG = D / 64, NF = 2 * KS2;
+  constexpr int NQ = 2 * KS2;                 // resident query fragments per wave
+  constexpr int NAQ = NQ < 32 ? NQ : 32;      // of which in AGPRs
+  constexpr int TILE_BYTES = kTileRows * D * 2;
+  constexpr int PIECES = KG / 2;              // DMA pieces per wave and tile (KG is even: D is a multiple of 128)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0..7
+  const int col = lane & 15, g = lane >> 4;
+
+  frag q[2][KS2];
+  {
+    const T* xq = (const T*)a.xq;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const uint32_t qi = wave * 32 + qb * 16 + col;
+      const T* p = xq + (size_t)(qi < a.nq ? qi : a.nq - 1) * D + 8 * g;
+#pragma unroll
+      for (int s2 = 0; s2 < KS2; ++s2) {
+        if (qb * KS2 + s2 < NAQ) agpr_load_frag(q[qb][s2], p + 32 * s2);
+        else q[qb][s2] = *(const frag*)(p + 32 * s2);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NAQ; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+a"(q[i / KS2][i % KS2]));
+  }
+
+  LaneState4 st;
+  const uint32_t nbuf = gridDim.x * 4;
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) {
+    const uint32_t qi = wave * 32 + (qb & 1) * 16 + col;
+    st.thr[qb] = (DENSE || qb >= 2) ? 0.f : a.thr[qi];
+    st.cnt[qb] = 0;
+    st.off[qb] = (qi * nbuf + blockIdx.x * 4 + g) * (uint32_t)a.cap;
+  }
+
+  uint32_t roff[2][2];
+  {
+    const int rho = col & 7;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int p = 2 * rb + (col >> 3);
+      const int f = ((rho >> 1) & 3) | ((p & 1) << 2);
+#pragma unroll
+      for (int par = 0; par < 2; ++par) roff[rb][par] = p * 1024 + rho * 128 + (((4 * par + g) ^ f) * 16);
+    }
+  }
+  // DMA: wave w fills row group p = w&3 of the k groups with parity w>>2
+  const int pw = wave & 3, kpar = wave >> 2;
+  const int rho_w = lane >> 3, sig = lane & 7;
+  const int f_w = ((rho_w >> 1) & 3) | ((pw & 1) << 2);
+  const int c_w = sig ^ f_w;
+  auto tile_src = [&](uint32_t j) -> const char* {
+    if (j >= a.n_tiles) j = a.n_tiles - 1;
+    const uint32_t tile = a.tile_first + j * a.tile_stride;
+    uint32_t row = tile * kTileRows + pw * 8 + rho_w;
+    row = row < a.n_rows ? row : a.n_rows - 1;
+    return (const char*)a.xb + (size_t)row * (D * 2) + c_w * 16 + kpar * 128;
+  };
+  auto issue_piece = [&](const char* gp, int slot, int i) {  // i-th piece of this wave: k group kpar + 2 i
+    char* l = smem + slot * TILE_BYTES + pw * 1024 + kpar * 4096;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + i * 256),
+                                     (__attribute__((address_space(3))) void*)(l + i * 8192), 16, 0, 0);
+  };
+  const int nb = __builtin_amdgcn_readfirstlane(
+      (int)a.nq <= wave * 32 ? 0 : ((int)a.nq - wave * 32 >= 32 ? 2 : ((int)a.nq - wave * 32 + 15) / 16));
+
+  uint32_t j = blockIdx.x;
+  const uint32_t stride = gridDim.x;
+  const uint32_t n_tiles = a.n_tiles;
+  if (j < n_tiles) {
+    const char* g0 = tile_src(j);
+    const char* g1 = tile_src(j + stride);
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) issue_piece(g0, 0, i);
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) issue_piece(g1, 1, i);
+  }
+  int slot = 0;
+  for (; j < n_tiles; j += stride) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    __builtin_amdgcn_s_barrier();
+    int nslot = slot + 2;
+    if (nslot >= 3) nslot -= 3;
+    const char* gn = tile_src(j + 2 * stride);
+    auto compute = [&](auto tag) {
+      constexpr int NQB = decltype(tag)::value;
+      f32x4 acc[2][4];
+      constexpr int NB = NF < 4 ? NF : 4;
+      frag c[NB];
+      uint32_t ab[2][2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int par = 0; par < 2; ++par) ab[rb][par] = (uint32_t)(slot * TILE_BYTES) + roff[rb][par];
+#pragma unroll
+      for (int f = 0; f < NB; ++f) lds_read_frag(c[f], ab[f & 1][(f >> 1) & 1], (f >> 2) * 4096);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int s2 = f >> 1, rb = f & 1;
+        if (NF - f >= NB) lgkm_wait<NB - 1>();
+        else if (NF - f == 3) lgkm_wait<2>();
+        else if (NF - f == 2) lgkm_wait<1>();
+        else lgkm_wait<0>();
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+          const bool in_a = qb * KS2 + s2 < NAQ;
+          if (s2 == 0) {
+            if (in_a) Mfma16Asm<T>::first_a(acc[rb][qb], c[f % NB], q[qb][0]);
+            else Mfma16Asm<T>::first_v(acc[rb][qb], c[f % NB], q[qb][0]);
+          } else {
+            if (in_a) Mfma16Asm<T>::acc_a(acc[rb][qb], c[f % NB], q[qb][s2]);
+            else Mfma16Asm<T>::acc_v(acc[rb][qb], c[f % NB], q[qb][s2]);
+          }
+        }
+        if (f + NB < NF) lds_read_frag(c[f % NB], ab[(f + NB) & 1][((f + NB) >> 1) & 1], ((f + NB) >> 2) * 4096);
+        if ((f & 7) == 3 && (f >> 3) < PIECES) issue_piece(gn, nslot, f >> 3);
+      }
+      if (NQB == 2) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+      else asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][0]));
+      tile_epilogue16<DENSE, NQB, 32>(a, st, acc, j, lane, wave);
+    };
+    if (nb == 2) {
+      compute(std::integral_constant<int, 2>{});
+    } else if (nb == 1) {
+      compute(std::integral_constant<int, 1>{});
+    } else {
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) issue_piece(gn, nslot, i);
+    }
+    slot = slot + 1;
+    if (slot >= 3) slot = 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!DENSE) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) a.cand_cnt[(wave * 32 + qb * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
   }
 }
 
@@ -770,7 +924,7 @@ static hipError_t launch_scan_generic(const ScanArgs& a, int D, bool dense, int 
 
 template <typename T> constexpr bool dtype_is_f16() { return false; }
 template <> constexpr bool dtype_is_f16<_Float16>() { return true; }
-int g_scan_variant = 16;  // 16 = 16x16x32 pipelined asm (default), 1 = 32x32x16 pipelined asm, 0 = compiler-scheduled, 3 = generic
+int g_scan_variant = 16;  // 16 = 16x16x32 pipelined asm (default); dev: 15 same w/o nt, 8 = 8-wave, 1 = 32x32x16 asm, 0 = compiler-scheduled, 3 = generic
 
 static void read_variant_env() {
   static const bool env_read = [] {
@@ -784,7 +938,7 @@ static void read_variant_env() {
 int scan_bufs_per_wg(int D) {
   read_variant_env();
   if (D > kMaxResidentDim || g_scan_variant == 3) return 4;  // generic kernel: 2 workgroups per CU x 2 lane halves
-  return g_scan_variant == 16 ? 4 : 2;
+  return (g_scan_variant == 0 || g_scan_variant == 1 || g_scan_variant == 2 || (g_scan_variant >= 4 && g_scan_variant <= 7) || g_scan_variant == 9 || g_scan_variant == 48) && D == 768 ? 2 : 4;
 }
 
 
@@ -798,32 +952,53 @@ static hipError_t launch_scan_v(const ScanArgs& a, int grid, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <typename T, int D, bool DENSE>
+template <typename T, int D, bool DENSE, bool NT = false>
 static hipError_t launch_scan16(const ScanArgs& a, int grid, hipStream_t st) {
   const size_t lds = 3 * (size_t)kTileRows * D * 2;
-  hipError_t e = hipFuncSetAttribute((const void*)flat_scan16_kernel<T, D, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute((const void*)flat_scan16_kernel<T, D, DENSE, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((flat_scan16_kernel<T, D, DENSE>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((flat_scan16_kernel<T, D, DENSE, NT>), dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
+template <typename T, int D, bool DENSE>
+static hipError_t launch_scan16x8(const ScanArgs& a, int grid, hipStream_t st) {
+  const size_t lds = 3 * (size_t)kTileRows * D * 2;
+  hipError_t e = hipFuncSetAttribute((const void*)flat_scan16x8_kernel<T, D, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((flat_scan16x8_kernel<T, D, DENSE>), dim3(grid), dim3(512), lds, st, a);
+  return hipGetLastError();
+}
+
+// Corpora beyond the 256 MiB Infinity Cache are streamed with non-temporal LDS-DMA (read once per batch: -1.7 % at
+// B=256, -11 % for single-query searches); smaller ones keep the default policy so back-to-back searches stay on die.
+constexpr size_t kNtThresholdBytes = 256ull << 20;
+
 template <typename T, int D>
 static hipError_t launch_scan_t(const ScanArgs& a, bool dense, int grid, hipStream_t st) {
-  if (g_scan_variant == 16) return dense ? launch_scan16<T, D, true>(a, grid, st) : launch_scan16<T, D, false>(a, grid, st);
-  if (g_scan_variant == 0)
-    return dense ? launch_scan_v<T, D, true, 0>(a, grid, st) : launch_scan_v<T, D, false, 0>(a, grid, st);
-  if (g_scan_variant == 2 && D == 768 && !dense) return launch_scan_v<T, 768, false, 2>(a, grid, st);
+  if (D == 768 && g_scan_variant != 16) {  // development variants (A/B, diagnostics) exist for the headline dimension only
+    constexpr int DV = 768;
+    if (g_scan_variant == 8) return dense ? launch_scan16x8<T, DV, true>(a, grid, st) : launch_scan16x8<T, DV, false>(a, grid, st);
+    if (g_scan_variant == 0) return dense ? launch_scan_v<T, DV, true, 0>(a, grid, st) : launch_scan_v<T, DV, false, 0>(a, grid, st);
+    if (g_scan_variant == 1) return dense ? launch_scan_v<T, DV, true, 1>(a, grid, st) : launch_scan_v<T, DV, false, 1>(a, grid, st);
+    if (g_scan_variant == 2 && !dense) return launch_scan_v<T, DV, false, 2>(a, grid, st);
+    if (g_scan_variant == 2) return launch_scan_v<T, DV, true, 1>(a, grid, st);
+    if (g_scan_variant == 15 && !dense) return launch_scan16<T, DV, false, false>(a, grid, st);  // 16x16x32 without nt
 #ifdef RR_ABLATION_VARIANTS
-  if (D == 768 && !dense) {
-    if (g_scan_variant == 4) return launch_scan_v<T, 768, false, 4>(a, grid, st);
-    if (g_scan_variant == 5) return launch_scan_v<T, 768, false, 5>(a, grid, st);
-    if (g_scan_variant == 6) return launch_scan_v<T, 768, false, 6>(a, grid, st);
-    if (g_scan_variant == 7) return launch_scan_v<T, 768, false, 7>(a, grid, st);
-    if (g_scan_variant == 8) return launch_scan_v<T, 768, false, 8>(a, grid, st);
-    if (g_scan_variant == 9 && dtype_is_f16<T>()) return launch_scan_v<T, 768, false, 9>(a, grid, st);
-  }
+    if (!dense) {
+      if (g_scan_variant == 4) return launch_scan_v<T, DV, false, 4>(a, grid, st);
+      if (g_scan_variant == 5) return launch_scan_v<T, DV, false, 5>(a, grid, st);
+      if (g_scan_variant == 6) return launch_scan_v<T, DV, false, 6>(a, grid, st);
+      if (g_scan_variant == 7) return launch_scan_v<T, DV, false, 7>(a, grid, st);
+      if (g_scan_variant == 48) return launch_scan_v<T, DV, false, 48>(a, grid, st);
+      if (g_scan_variant == 9 && dtype_is_f16<T>()) return launch_scan_v<T, DV, false, 9>(a, grid, st);
+    }
+    if (g_scan_variant >= 4) return launch_scan_v<T, DV, true, 1>(a, grid, st);
 #endif
-  return dense ? launch_scan_v<T, D, true, 1>(a, grid, st) : launch_scan_v<T, D, false, 1>(a, grid, st);
+  }
+  if (dense) return launch_scan16<T, D, true, false>(a, grid, st);
+  const bool nt = (size_t)a.n_rows * D * 2 > kNtThresholdBytes;
+  return nt ? launch_scan16<T, D, false, true>(a, grid, st) : launch_scan16<T, D, false, false>(a, grid, st);
 }
 
 template <typename T>
