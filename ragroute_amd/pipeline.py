@@ -10,7 +10,7 @@ Everything is enqueued on the current stream; nothing synchronises with the host
 import torch
 
 from .rerank import merge_topk
-from .sharded import SHARD_SHIFT, gather_candidates
+from .sharded import SHARD_SHIFT, alloc_packed, gather_candidates, gather_packed
 
 
 class RetrievalPipeline:
@@ -21,6 +21,7 @@ class RetrievalPipeline:
         self.shard_ids = [int(s) for s in shard_ids]
         self.router = router
         self.group = group
+        self._packed = {}
 
     def route(self, xq_models):
         """xq_models: f32 [B, n_models, d_max] -> (logits, bool mask [B, C]) on device, or (None, None) for 'all'."""
@@ -31,12 +32,23 @@ class RetrievalPipeline:
     def search(self, xq, k, xq_models=None):
         """xq: f32 CUDA [B, d] query embeddings for the shards; xq_models: router input (defaults to xq as the single model)."""
         _, mask = self.route(xq[:, None, :].contiguous() if xq_models is None else xq_models)
+        B = xq.shape[0]
+        if len(self.shards) == 1:
+            # one shard per rank (the benchmark layout): results land in a packed buffer, ONE collective moves it
+            key = (B, k)
+            if key not in self._packed:
+                self._packed = {key: alloc_packed(B, k, xq.device)}
+            buf, D, I = self._packed[key]
+            idx, sid = self.shards[0], self.shard_ids[0]
+            idx.search_prepared(idx.prepare_queries(xq), k, id_offset=sid << SHARD_SHIFT, out=(D, I),
+                                route_mask=None if mask is None else mask[:, sid])
+            Dg, Ig = gather_packed(buf, B, k, self.group)
+            return merge_topk(Dg, Ig, k, True)
         Ds, Is = [], []
         for idx, sid in zip(self.shards, self.shard_ids):
             D, I = idx.search_prepared(idx.prepare_queries(xq), k, id_offset=sid << SHARD_SHIFT,
                                        route_mask=None if mask is None else mask[:, sid])
             Ds.append(D)
             Is.append(I)
-        D, I = (Ds[0], Is[0]) if len(Ds) == 1 else (torch.cat(Ds, 1), torch.cat(Is, 1))
-        Dg, Ig = gather_candidates(D, I, self.group)
+        Dg, Ig = gather_candidates(torch.cat(Ds, 1), torch.cat(Is, 1), self.group)
         return merge_topk(Dg, Ig, k, True)

@@ -48,6 +48,37 @@ def gather_candidates(D, I, group=None):
             Ig.view(world, B, k).permute(1, 0, 2).reshape(B, world * k))
 
 
+def alloc_packed(B, k, device):
+    """One allocation holding D f32[B,k] followed by I i64[B,k]: the kernels write straight into the two views and the
+    exchange moves the whole buffer with ONE collective."""
+    nD = B * k * 4
+    pad = (-nD) % 8
+    buf = torch.empty(nD + pad + B * k * 8, dtype=torch.uint8, device=device)
+    D = buf[:nD].view(torch.float32).view(B, k)
+    I = buf[nD + pad:].view(torch.int64).view(B, k)
+    return buf, D, I
+
+
+def gather_packed(buf, B, k, group=None):
+    """all_gather of packed candidate buffers (see alloc_packed) -> ([B, G*k] scores, [B, G*k] ids), rank-major columns."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    nD = B * k * 4
+    pad = (-nD) % 8
+    if world == 1:
+        return buf[:nD].view(torch.float32).view(B, k), buf[nD + pad:].view(torch.int64).view(B, k)
+    if buf.is_cuda and dist.get_backend(group) == "gloo":  # rehearsal on one box: stage through the host
+        out = torch.empty(world * buf.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(out, buf.cpu(), group=group)
+        out = out.to(buf.device)
+    else:
+        out = torch.empty(world * buf.numel(), dtype=torch.uint8, device=buf.device)
+        dist.all_gather_into_tensor(out, buf, group=group)
+    out = out.view(world, buf.numel())
+    Dg = out[:, :nD].contiguous().view(torch.float32).view(world, B, k).permute(1, 0, 2).reshape(B, world * k)
+    Ig = out[:, nD + pad:].contiguous().view(torch.int64).view(world, B, k).permute(1, 0, 2).reshape(B, world * k)
+    return Dg, Ig
+
+
 class ShardedFlatSearch:
     """This rank's shards (FlatIndex objects) + the exchange/merge step."""
 

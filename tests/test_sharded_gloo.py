@@ -35,6 +35,12 @@ def _worker(rank, world, port, out_dir):
         assert tuple(Dg.shape) == (6, world * k)
         # rank-major column blocks
         assert torch.equal(Dg[:, rank * k:(rank + 1) * k], Dm) and torch.equal(Ig[:, rank * k:(rank + 1) * k], Im)
+        # the packed single-collective form must give the same layout
+        buf, Dp, Ip = S.alloc_packed(6, k, "cpu")
+        Dp.copy_(Dm)
+        Ip.copy_(Im)
+        Dg2, Ig2 = S.gather_packed(buf, 6, k)
+        assert torch.equal(Dg2, Dg) and torch.equal(Ig2, Ig)
         Do, Io = O.merge_topk(Dg.numpy(), Ig.numpy(), k, True)
         # expectation: per query, oracle search over the union of the shards the mask selects
         for q in range(6):
