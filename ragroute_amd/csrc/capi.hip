@@ -169,8 +169,9 @@ int rr_flat_search(const void* xb, int dtype, int64_t n_rows, int dim, const voi
   hipError_t e;
 #define RR_CHECK(call, what) do { e = (call); if (e != hipSuccess) return hip_fail(e, what); } while (0)
 
-  for (int qb = 0; qb < nq; qb += kQueriesPerBlock) {
-    const int nqb = nq - qb < kQueriesPerBlock ? nq - qb : kQueriesPerBlock;
+  const int qpl = scan_queries_per_launch(dim);  // 256, or 128 where only 32 queries per wave stay resident
+  for (int qb = 0; qb < nq; qb += qpl) {
+    const int nqb = nq - qb < qpl ? nq - qb : qpl;
     const char* xq_b = (const char*)xq + (size_t)qb * dim * 2;
     float* D_b = D + (size_t)qb * k;
     int64_t* I_b = I + (size_t)qb * k;

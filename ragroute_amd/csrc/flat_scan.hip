@@ -822,6 +822,193 @@ __global__ __launch_bounds__(512, 2) void flat_scan16x8_kernel(const ScanArgs a)
   }
 }
 
+// ---- 768 < D <= 1536 (FeB4RAG's 1024-wide encoders): resident queries, half-tile ring --------------------------
+// 32 queries per wave stay resident (2 blocks of 16: D/4 registers), so one launch serves 128 queries and a 256-query
+// block takes two passes over the corpus (each pass runs near the HBM rate because it carries half the MFMA work).
+// The LDS ring works on 16-row half tiles (16 x D x 2 bytes: 32 KB at D = 1024 -> 4 slots, 48 KB at 1536 -> 3 slots).
+template <typename T, int D, bool DENSE, bool NT>
+__global__ __launch_bounds__(256, 1) void flat_scan16h_kernel(const ScanArgs a) {
+  typedef typename Mfma<T>::frag frag;
+  constexpr int KS2 = D / 32, KG = D / 64;
+  constexpr int UNIT_BYTES = 16 * D * 2;
+  constexpr int NSLOT = (160 * 1024) / UNIT_BYTES >= 4 ? 4 : 3;
+  constexpr int AHEAD = NSLOT - 1;            // units in flight ahead of the one being multiplied
+  constexpr int PIECES = KG / 2;              // DMA pieces per wave and unit: 2 row groups x KG k groups over 4 waves
+  constexpr int NQ = 2 * KS2;
+  constexpr int NAQ = NQ < 62 ? NQ : 62;
+  static_assert(KG % 2 == 0, "D must be a multiple of 128");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 15, g = lane >> 4;
+
+  frag q[2][KS2];
+  {
+    const T* xq = (const T*)a.xq;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const uint32_t qi = wave * 32 + qb * 16 + col;
+      const T* p = xq + (size_t)(qi < a.nq ? qi : a.nq - 1) * D + 8 * g;
+#pragma unroll
+      for (int s2 = 0; s2 < KS2; ++s2) {
+        if (qb * KS2 + s2 < NAQ) agpr_load_frag(q[qb][s2], p + 32 * s2);
+        else q[qb][s2] = *(const frag*)(p + 32 * s2);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NAQ; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+a"(q[i / KS2][i % KS2]));
+  }
+  float thr[2];
+  uint32_t cnt[2], off[2];
+  const uint32_t nbuf = gridDim.x * 4;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const uint32_t qi = wave * 32 + qb * 16 + col;
+    thr[qb] = DENSE ? 0.f : a.thr[qi];
+    cnt[qb] = 0;
+    off[qb] = (qi * nbuf + blockIdx.x * 4 + g) * (uint32_t)a.cap;
+  }
+  // A fragment of slice s2 in a 16-row unit: row col (row group p = col>>3), chunk 4*(s2&1) + g of k group s2>>1;
+  // unit image: piece (kg, p) at (kg*2 + p) * 1024
+  uint32_t roff[2];
+  {
+    const int p = col >> 3, rho = col & 7;
+    const int f = ((rho >> 1) & 3) | (p << 2);
+#pragma unroll
+    for (int par = 0; par < 2; ++par) roff[par] = p * 1024 + rho * 128 + (((4 * par + g) ^ f) * 16);
+  }
+  // DMA: wave w fills row group p = w&1 of the k groups with parity w>>1
+  const int pw = wave & 1, kpar = wave >> 1;
+  const int rho_w = lane >> 3, sig = lane & 7;
+  const int f_w = ((rho_w >> 1) & 3) | (pw << 2);
+  const int c_w = sig ^ f_w;
+  // unit ordinal u = 2*i + half, i-th tile of this workgroup (tile ordinal j = blockIdx + i*gridDim)
+  const uint32_t my_tiles = a.n_tiles > blockIdx.x ? (a.n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const uint32_t n_units = 2 * my_tiles;
+  auto unit_src = [&](uint32_t u) -> const char* {
+    if (u >= n_units) u = n_units - 1;
+    const uint32_t j = blockIdx.x + (u >> 1) * gridDim.x;
+    const uint32_t tile = a.tile_first + j * a.tile_stride;
+    uint32_t row = tile * kTileRows + (u & 1) * 16 + pw * 8 + rho_w;
+    row = row < a.n_rows ? row : a.n_rows - 1;
+    return (const char*)a.xb + (size_t)row * (D * 2) + c_w * 16 + kpar * 128;
+  };
+  auto issue_piece = [&](const char* gp, int slot, int i) {  // i-th piece: k group kpar + 2 i
+    char* l = smem + slot * UNIT_BYTES + pw * 1024 + kpar * 2048;
+    if (NT)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + i * 256),
+                                       (__attribute__((address_space(3))) void*)(l + i * 4096), 16, 0, 2);
+    else
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + i * 256),
+                                       (__attribute__((address_space(3))) void*)(l + i * 4096), 16, 0, 0);
+  };
+  const int nb = __builtin_amdgcn_readfirstlane(
+      (int)a.nq <= wave * 32 ? 0 : ((int)a.nq - wave * 32 >= 32 ? 2 : ((int)a.nq - wave * 32 + 15) / 16));
+
+  if (n_units > 0) {
+#pragma unroll
+    for (int h = 0; h < AHEAD; ++h) {
+      const char* g0 = unit_src(h);
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) issue_piece(g0, h, i);
+    }
+  }
+  int slot = 0;
+  for (uint32_t u = 0; u < n_units; ++u) {
+    // unit u landed: all but the (AHEAD-1)*PIECES youngest DMA ops are done
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PIECES) : "memory");
+    __builtin_amdgcn_s_barrier();
+    int nslot = slot + AHEAD;
+    if (nslot >= NSLOT) nslot -= NSLOT;
+    const char* gn = unit_src(u + AHEAD);
+    const uint32_t j = blockIdx.x + (u >> 1) * gridDim.x;
+    const uint32_t row0 = (a.tile_first + j * a.tile_stride) * kTileRows + (u & 1) * 16 + 4 * g;
+    if (nb > 0) {
+      f32x4 acc[2];
+      constexpr int NB = KS2 < 8 ? KS2 : 8;
+      frag c[NB];
+      uint32_t ab[2];
+      ab[0] = (uint32_t)(slot * UNIT_BYTES) + roff[0];
+      ab[1] = (uint32_t)(slot * UNIT_BYTES) + roff[1];
+#pragma unroll
+      for (int f = 0; f < NB; ++f) lds_read_frag(c[f], ab[f & 1], (f >> 1) * 2048);
+#pragma unroll
+      for (int f = 0; f < KS2; ++f) {
+        if (KS2 - f >= NB) lgkm_wait<NB - 1>();
+        else if (KS2 - f == 7) lgkm_wait<6>();
+        else if (KS2 - f == 6) lgkm_wait<5>();
+        else if (KS2 - f == 5) lgkm_wait<4>();
+        else if (KS2 - f == 4) lgkm_wait<3>();
+        else if (KS2 - f == 3) lgkm_wait<2>();
+        else if (KS2 - f == 2) lgkm_wait<1>();
+        else lgkm_wait<0>();
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          const bool in_a = qb * KS2 + f < NAQ;
+          if (f == 0) {
+            if (in_a) Mfma16Asm<T>::first_a(acc[qb], c[0], q[qb][0]);
+            else Mfma16Asm<T>::first_v(acc[qb], c[0], q[qb][0]);
+          } else {
+            if (in_a) Mfma16Asm<T>::acc_a(acc[qb], c[f % NB], q[qb][f]);
+            else Mfma16Asm<T>::acc_v(acc[qb], c[f % NB], q[qb][f]);
+          }
+        }
+        if (f + NB < KS2) lds_read_frag(c[f % NB], ab[(f + NB) & 1], ((f + NB) >> 1) * 2048);
+        if ((f & 3) == 1 && (f >> 2) < PIECES) issue_piece(gn, nslot, f >> 2);
+      }
+      asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+      if (DENSE) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+          *(f32x4*)(a.dense + (size_t)(wave * 32 + qb * 16 + col) * a.dense_ld + j * kTileRows + (u & 1) * 16 + 4 * g) = acc[qb];
+      } else {
+        const float m0 = max4v(acc[0]), m1 = max4v(acc[1]);
+        if (__builtin_amdgcn_ballot_w64(m0 > thr[0] || m1 > thr[1])) {
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const uint32_t id = row0 + i;
+              if (acc[qb][i] > thr[qb] && id < a.n_rows) {
+                a.cand[(size_t)off[qb] + cnt[qb]] = make_key(acc[qb][i], id);
+                ++cnt[qb];
+              }
+            }
+          }
+          const uint32_t lim = (uint32_t)a.cap - 16u;
+          if (__builtin_amdgcn_ballot_w64(cnt[0] > lim || cnt[1] > lim)) {
+            uint64_t* scratch = a.scratch + (size_t)(blockIdx.x * 4 + wave) * a.cap;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+              uint64_t mask = __builtin_amdgcn_ballot_w64(cnt[qb] > lim);
+              while (mask) {
+                const int L = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const uint32_t o = __shfl(off[qb], L, 64);
+                const int cn = (int)__shfl(cnt[qb], L, 64);
+                const uint64_t kth = wave_compact(a.cand + (size_t)__builtin_amdgcn_readfirstlane(o), scratch,
+                                                  __builtin_amdgcn_readfirstlane(cn), a.k, lane);
+                if (lane == L) { cnt[qb] = a.k; thr[qb] = key_score(kth); }
+              }
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) issue_piece(gn, nslot, i);
+    }
+    slot = slot + 1;
+    if (slot >= NSLOT) slot = 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!DENSE) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) a.cand_cnt[(wave * 32 + qb * 16 + col) * nbuf + blockIdx.x * 4 + g] = cnt[qb];
+  }
+}
+
 // ---- generic embedding dimension (any multiple of 64, e.g. 1024 / 4096 of FeB4RAG, config.py:45-57) ------------
 // Queries no longer fit the register file, so they are re-streamed from L2 per 64-wide K step (each wave loads only
 // its own 64 queries: nothing to share, no LDS hop); the corpus goes global -> registers -> LDS (same XOR-swizzled
@@ -914,6 +1101,35 @@ __global__ __launch_bounds__(256, 2) void flat_scan_generic_kernel(const ScanArg
   }
 }
 
+template <typename T, int D>
+static hipError_t launch_scan16h(const ScanArgs& a, bool dense, int grid, hipStream_t st) {
+  constexpr int unit = 16 * D * 2;
+  constexpr int nslot = (160 * 1024) / unit >= 4 ? 4 : 3;
+  const size_t lds = (size_t)nslot * unit;
+  const bool nt = !dense && (size_t)a.n_rows * D * 2 > (256ull << 20);
+  hipError_t e;
+#define RR_LAUNCH_H(DENSE_, NT_)                                                                                      \
+  e = hipFuncSetAttribute((const void*)flat_scan16h_kernel<T, D, DENSE_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+  if (e != hipSuccess) return e;                                                                                      \
+  hipLaunchKernelGGL((flat_scan16h_kernel<T, D, DENSE_, NT_>), dim3(grid), dim3(256), lds, st, a);
+  if (dense) { RR_LAUNCH_H(true, false) }
+  else if (nt) { RR_LAUNCH_H(false, true) }
+  else { RR_LAUNCH_H(false, false) }
+#undef RR_LAUNCH_H
+  return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_scan_half_resident(const ScanArgs& a, int D, bool dense, int grid, hipStream_t st) {
+  switch (D) {
+    case 896: return launch_scan16h<T, 896>(a, dense, grid, st);
+    case 1024: return launch_scan16h<T, 1024>(a, dense, grid, st);
+    case 1280: return launch_scan16h<T, 1280>(a, dense, grid, st);
+    case 1536: return launch_scan16h<T, 1536>(a, dense, grid, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 template <typename T>
 static hipError_t launch_scan_generic(const ScanArgs& a, int D, bool dense, int grid, hipStream_t st) {
   // two workgroups per CU (<= 256 registers per lane, 16 KB LDS): thread-level parallelism hides the L2 / barrier latency
@@ -932,6 +1148,13 @@ static void read_variant_env() {
     return true;
   }();
   (void)env_read;
+}
+
+// queries one scan launch serves for this dim: 256, or 128 for the half-resident kernel (768 < D <= 1536)
+int scan_queries_per_launch(int D) {
+  read_variant_env();
+  if (g_scan_variant == 3) return 256;
+  return (D == 896 || D == 1024 || D == 1280 || D == 1536) ? 128 : 256;
 }
 
 // candidate buffers per (workgroup, query) of the kernel that will serve this dim
@@ -1016,6 +1239,11 @@ static hipError_t launch_scan_d(const ScanArgs& a, int D, bool dense, int grid, 
 
 hipError_t launch_flat_scan(const ScanArgs& a, int dtype, int D, bool dense, int grid, hipStream_t st) {
   read_variant_env();
+  if (scan_queries_per_launch(D) == 128) {  // 768 < D <= 1536: 32 resident queries per wave, half-tile ring
+    if (dtype == RR_DTYPE_F16) return launch_scan_half_resident<_Float16>(a, D, dense, grid, st);
+    if (dtype == RR_DTYPE_BF16) return launch_scan_half_resident<__bf16>(a, D, dense, grid, st);
+    return hipErrorInvalidValue;
+  }
   if (D > kMaxResidentDim || g_scan_variant == 3) {  // generic-dimension kernel (also forced by RR_SCAN_VARIANT=3)
     if (D % 64 != 0) return hipErrorInvalidValue;
     if (dtype == RR_DTYPE_F16) return launch_scan_generic<_Float16>(a, D, dense, grid, st);
@@ -1028,9 +1256,10 @@ hipError_t launch_flat_scan(const ScanArgs& a, int dtype, int D, bool dense, int
 }
 
 int scan_padded_dim(int d) {
-  static const int dims[] = {128, 256, 384, 512, 640, 768};  // query-resident instantiations
+  static const int dims[] = {128, 256, 384, 512, 640, 768, 896, 1024, 1280, 1536};  // query-resident instantiations
+  read_variant_env();
   for (int v : dims)
-    if (d <= v) return v;
+    if (d <= v && (v <= kMaxResidentDim || g_scan_variant != 3)) return v;
   if (d <= kMaxDim) return (d + 63) / 64 * 64;  // generic kernel
   return -1;
 }
