@@ -178,6 +178,9 @@ def cpu_baseline(idx, xq, n, d, k):
     Bounded sample: the shard's first 1M rows, as many single-query calls as fit in ~10 s; the rate is scaled
     linearly in rows to the full shard."""
     from oracle import oracle as O
+    # the CPUs this process may really use: affinity mask, capped at the 1-GPU box's CPU share
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    O.set_threads(max(1, min(usable, int(os.environ.get("RR_CPU_BASELINE_THREADS", 16)))))
     sample = min(n, 1_000_000)
     xb = idx.xb[:sample, :d].float().cpu().numpy()
     q = xq.cpu().numpy().astype(np.float32)
@@ -188,9 +191,23 @@ def cpu_baseline(idx, xq, n, d, k):
         calls += 1
     dt = time.perf_counter() - t0
     qps_sample = calls / dt
+    # parity on the same sample: GPU top-k of the first `sample` rows vs the oracle (f64 scores of the same fp16 values)
+    from ragroute_amd.flat_index import FlatIndex
+    nchk = 32
+    sub = FlatIndex(d, dtype=idx.dtype, device=idx.device)
+    sub.adopt(idx.xb[:sample])
+    Dg, Ig = sub.search_prepared(sub.prepare_queries(xq[:nchk]), k)
+    Dg, Ig = Dg.cpu().numpy(), Ig.cpu().numpy()
+    qh = sub.prepare_queries(xq[:nchk])[:, :d].float().cpu().numpy()
+    Dr, Ir = O.flat_search_ip(xb, qh, k)
+    recall = float(np.mean([len(set(Ig[i]) & set(Ir[i])) / k for i in range(nchk)]))
+    parity = {"recall_at_k": round(recall, 6), "rank_order_identical_queries": int(sum(np.array_equal(Ig[i], Ir[i]) for i in range(nchk))),
+              "queries_checked": nchk, "max_abs_score_diff": float(np.abs(Dg - Dr).max()),
+              "sample": f"GPU top-{k} of the first {sample} rows vs oracle.flat_search_ip (f64 dot products of the same fp16-rounded values)"}
     return {"value": round(qps_sample * sample / n, 3), "unit": "queries/sec", "cores": O.num_threads(), "kind": "port",
             "sample": f"{calls} single-query f32 searches (nq=1 per call, as the reference issues them) over the first {sample} rows "
-                      f"in {dt:.2f} s = {qps_sample:.2f} q/s on the sample, scaled x{sample / n:.3g} to {n} rows"}
+                      f"in {dt:.2f} s = {qps_sample:.2f} q/s on the sample, scaled x{sample / n:.3g} to {n} rows",
+            "parity_vs_cpu": parity}
 
 
 if __name__ == "__main__":

@@ -31,6 +31,14 @@ int oracle_num_threads(void) {
 #endif
 }
 
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 /* a is better than b: higher score, then lower id */
 static int better(float sa, int64_t ia, float sb, int64_t ib) { return sa > sb || (sa == sb && ia < ib); }
 

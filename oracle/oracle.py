@@ -52,6 +52,8 @@ def _lib():
         lib.oracle_merge_topk.argtypes = [f32p, i64p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, f32p, i64p]
         lib.oracle_merge_topk.restype = None
         lib.oracle_num_threads.restype = ctypes.c_int
+        lib.oracle_set_threads.argtypes = [ctypes.c_int]
+        lib.oracle_set_threads.restype = None
         _LIB = lib
     return _LIB
 
@@ -66,6 +68,11 @@ def _i64(a):
 
 def num_threads():
     return int(_lib().oracle_num_threads())
+
+
+def set_threads(n):
+    """Cap the OpenMP team (bench.py sizes it to the CPUs this process may actually use)."""
+    _lib().oracle_set_threads(int(n))
 
 
 # ---- a2: index.search — data_source.py:158, 186, 203 -----------------------------------------

@@ -44,7 +44,7 @@ def test_gaussian_fp16(gpu):
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
-@pytest.mark.parametrize("d,k", [(100, 10), (384, 32), (768, 100), (800, 10), (1024, 10), (4096, 10)])
+@pytest.mark.parametrize("d,k", [(100, 10), (384, 32), (768, 100), (800, 10), (1024, 10), (1536, 32), (4096, 10)])
 def test_dims_and_dtypes(gpu, dtype, d, k):
     from oracle import oracle as O
     rng = np.random.default_rng(d + k)
