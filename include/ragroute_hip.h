@@ -82,6 +82,16 @@ int rr_flat_search(const void* d_xb, int dtype, int64_t n_rows, int dim, const v
                    float* d_D, int64_t* d_I, int64_t id_offset, void* d_ws, size_t ws_bytes,
                    const uint8_t* d_route_mask, int64_t mask_stride, void* stream);
 
+/* The same search under the squared-L2 metric (the role of faiss.IndexFlatL2: the reference's index files decide the metric,
+ * data_source.py:71; its wikipedia merge keeps the LOWEST scores, rerank.py:30, i.e. treats scores as distances).  Returns
+ * the k nearest rows, nearest first, d_D = |q - x|^2, ties by ascending id, padding (+inf, -1).
+ *   d_half_sqnorm  device f32 [n_rows]: |x|^2 / 2 of every stored row (rr_half_sqnorms).  dim <= 768 in this build. */
+int rr_flat_search_l2(const void* d_xb, const float* d_half_sqnorm, int dtype, int64_t n_rows, int dim, const void* d_xq,
+                      int nq, int k, float* d_D, int64_t* d_I, int64_t id_offset, void* d_ws, size_t ws_bytes,
+                      const uint8_t* d_route_mask, int64_t mask_stride, void* stream);
+/* |x|^2 / 2 (f32) of every row of a stored corpus, computed from the stored (rounded) values. */
+int rr_half_sqnorms(const void* d_xb, int dtype, int64_t n_rows, int dim, float* d_out, void* stream);
+
 /* Measurement aid (bench.py): between rr_profile_begin and rr_profile_end every launch of the scan
  * kernel made by rr_flat_search on the calling thread is bracketed by HIP events on the launch stream.
  * rr_profile_end waits for them and returns the summed kernel time, the number of launches and the

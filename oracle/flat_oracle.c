@@ -69,6 +69,25 @@ void oracle_flat_search_ip(const float* xb, int64_t n, int d, const float* xq, i
   }
 }
 
+/* Flat squared-L2 index (faiss.IndexFlatL2 contract): k nearest rows, nearest first, D = |q - x|^2 (f32 rounding of an f64
+ * sum), ties by ascending id, padding (+inf, -1). */
+void oracle_flat_search_l2(const float* xb, int64_t n, int d, const float* xq, int nq, int k, float* D, int64_t* I) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int q = 0; q < nq; ++q) {
+    float* Dq = D + (size_t)q * k; int64_t* Iq = I + (size_t)q * k;
+    int cnt = 0;
+    const float* x = xq + (size_t)q * d;
+    for (int64_t r = 0; r < n; ++r) {
+      const float* y = xb + (size_t)r * d;
+      double acc = 0.0;
+      for (int j = 0; j < d; ++j) { const double t = (double)x[j] - (double)y[j]; acc += t * t; }
+      topk_insert(Dq, Iq, &cnt, k, -(float)acc, r);
+    }
+    for (int j = 0; j < cnt; ++j) Dq[j] = -Dq[j];
+    for (int j = cnt; j < k; ++j) { Dq[j] = INFINITY; Iq[j] = -1; }
+  }
+}
+
 /* The reference's actual call pattern: ONE query per call (data_source.py:114), f32 arithmetic
  * as a CPU flat index does it, rows split over the host cores.  Used as bench.py's cpu_baseline. */
 void oracle_flat_search_ip_f32_single(const float* xb, int64_t n, int d, const float* xq, int k, float* D, int64_t* I) {

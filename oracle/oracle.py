@@ -45,6 +45,8 @@ def _lib():
         f32p, i64p = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64)
         lib.oracle_flat_search_ip.argtypes = [f32p, ctypes.c_int64, ctypes.c_int, f32p, ctypes.c_int, ctypes.c_int, f32p, i64p]
         lib.oracle_flat_search_ip.restype = None
+        lib.oracle_flat_search_l2.argtypes = [f32p, ctypes.c_int64, ctypes.c_int, f32p, ctypes.c_int, ctypes.c_int, f32p, i64p]
+        lib.oracle_flat_search_l2.restype = None
         lib.oracle_flat_search_ip_f32_single.argtypes = [f32p, ctypes.c_int64, ctypes.c_int, f32p, ctypes.c_int, f32p, i64p]
         lib.oracle_flat_search_ip_f32_single.restype = None
         lib.oracle_normalize_l2.argtypes = [f32p, ctypes.c_int64, ctypes.c_int64]
@@ -85,6 +87,18 @@ def flat_search_ip(xb, xq, k):
     D = np.empty((nq, k), np.float32)
     I = np.empty((nq, k), np.int64)
     _lib().oracle_flat_search_ip(_f32(xb), xb.shape[0], d, _f32(xq), nq, k, _f32(D), _i64(I))
+    return D, I
+
+
+def flat_search_l2(xb, xq, k):
+    """faiss.IndexFlatL2 contract: (D = squared L2 distances f32[nq,k] ascending, I i64[nq,k]); ties by ascending id;
+    (+inf, -1) padding.  Not used by the reference's code directly (the index FILE decides the metric, data_source.py:71)."""
+    xb = np.ascontiguousarray(xb, dtype=np.float32)
+    xq = np.ascontiguousarray(xq, dtype=np.float32)
+    nq, d = xq.shape
+    D = np.empty((nq, k), np.float32)
+    I = np.empty((nq, k), np.int64)
+    _lib().oracle_flat_search_l2(_f32(xb), xb.shape[0], d, _f32(xq), nq, k, _f32(D), _i64(I))
     return D, I
 
 

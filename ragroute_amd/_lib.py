@@ -13,7 +13,7 @@ RR_QUERY_BLOCK = 256
 
 EXPORTS = ("rr_version", "rr_last_error", "rr_device_cus", "rr_padded_dim", "rr_l2_normalize_f32", "rr_rows_to_half",
            "rr_flat_search_workspace_bytes", "rr_flat_search", "rr_merge_topk", "rr_router_mlp", "rr_profile_begin",
-           "rr_profile_end", "rr_centroid")
+           "rr_profile_end", "rr_centroid", "rr_flat_search_l2", "rr_half_sqnorms")
 
 
 class RouterWeightsStruct(ctypes.Structure):
@@ -55,6 +55,8 @@ def lib():
         L.rr_flat_search.argtypes = [vp, i32, i64, i32, vp, i32, i32, vp, vp, i64, vp, sz, vp, i64, vp]
         L.rr_merge_topk.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
         L.rr_router_mlp.argtypes = [ctypes.POINTER(RouterWeightsStruct), vp, i32, vp, vp, vp]
+        L.rr_flat_search_l2.argtypes = [vp, vp, i32, i64, i32, vp, i32, i32, vp, vp, i64, vp, sz, vp, i64, vp]
+        L.rr_half_sqnorms.argtypes = [vp, i32, i64, i32, vp, vp]
         L.rr_centroid.argtypes = [vp, i32, i64, i32, i32, vp, vp]
         L.rr_profile_begin.argtypes = [i32]
         L.rr_profile_end.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]

@@ -145,9 +145,9 @@ size_t rr_flat_search_workspace_bytes(int k) {
   return carve(nullptr, k, grid).total;
 }
 
-int rr_flat_search(const void* xb, int dtype, int64_t n_rows, int dim, const void* xq, int nq, int k, float* D,
-                   int64_t* I, int64_t id_offset, void* ws, size_t ws_bytes, const uint8_t* route_mask,
-                   int64_t mask_stride, void* stream) {
+static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, const void* xq, int nq, int k, float* D,
+                            int64_t* I, int64_t id_offset, void* ws, size_t ws_bytes, const uint8_t* route_mask,
+                            int64_t mask_stride, const float* half_sqnorm, void* stream) {
   using namespace rr;
   hipStream_t st = (hipStream_t)stream;
   if (k < 1 || k > kMaxK) return fail(RR_ERR_INVALID, "rr_flat_search: k must be in [1, 1024]%s");
@@ -185,6 +185,7 @@ int rr_flat_search(const void* xb, int dtype, int64_t n_rows, int dim, const voi
     memset(&a, 0, sizeof(a));
     a.xb = xb; a.xq = xq_b; a.thr = w.thr; a.cand = w.cand; a.cand_cnt = w.cand_cnt; a.scratch = w.scratch;
     a.dense = w.dense; a.n_rows = (uint32_t)n_rows; a.nq = (uint32_t)nqb; a.dense_ld = kSampleRows; a.cap = cap; a.k = k;
+    a.half_sqnorm = half_sqnorm;
 
     RR_CHECK(launch_init_state(s, st), "rr_flat_search/init");
     if (n_rows > 0 && n_rows <= kDenseMaxRows) {
@@ -211,11 +212,38 @@ int rr_flat_search(const void* xb, int dtype, int64_t n_rows, int dim, const voi
         end *= g_chunk_growth;
       }
     }
-    RR_CHECK(launch_finalize(s, D_b, I_b, id_offset, route_mask ? route_mask + (size_t)qb * mask_stride : nullptr, mask_stride, st),
+    RR_CHECK(launch_finalize(s, D_b, I_b, id_offset, route_mask ? route_mask + (size_t)qb * mask_stride : nullptr, mask_stride,
+                             half_sqnorm ? (const void*)xq_b : nullptr, dtype, dim, st),
              "rr_flat_search/finalize");
   }
 #undef RR_CHECK
   return RR_OK;
+}
+
+int rr_flat_search(const void* xb, int dtype, int64_t n_rows, int dim, const void* xq, int nq, int k, float* D,
+                   int64_t* I, int64_t id_offset, void* ws, size_t ws_bytes, const uint8_t* route_mask,
+                   int64_t mask_stride, void* stream) {
+  return flat_search_impl(xb, dtype, n_rows, dim, xq, nq, k, D, I, id_offset, ws, ws_bytes, route_mask, mask_stride, nullptr, stream);
+}
+
+int rr_flat_search_l2(const void* xb, const float* half_sqnorm, int dtype, int64_t n_rows, int dim, const void* xq, int nq, int k,
+                      float* D, int64_t* I, int64_t id_offset, void* ws, size_t ws_bytes, const uint8_t* route_mask,
+                      int64_t mask_stride, void* stream) {
+  if (!half_sqnorm && n_rows > 0) return fail(RR_ERR_INVALID, "rr_flat_search_l2: null half_sqnorm%s");
+  if (dim > rr::kMaxResidentDim) return fail(RR_ERR_UNSUPPORTED, "rr_flat_search_l2: the L2 metric needs dim <= 768 in this build%s");
+  if (n_rows == 0) {  // nothing to rank: emit padding through the common path (half_sqnorm unused)
+    static const float dummy = 0.f;
+    (void)dummy;
+  }
+  return flat_search_impl(xb, dtype, n_rows, dim, xq, nq, k, D, I, id_offset, ws, ws_bytes, route_mask, mask_stride,
+                          half_sqnorm ? half_sqnorm : (const float*)xb /* never dereferenced when n_rows == 0 */, stream);
+}
+
+int rr_half_sqnorms(const void* xb, int dtype, int64_t n_rows, int dim, float* out, void* stream) {
+  if (n_rows < 0 || dim < 8 || dim % 8 != 0 || ((!xb || !out) && n_rows > 0)) return fail(RR_ERR_INVALID, "rr_half_sqnorms: bad arguments%s");
+  if (dtype != RR_DTYPE_F16 && dtype != RR_DTYPE_BF16) return fail(RR_ERR_INVALID, "rr_half_sqnorms: bad dtype%s");
+  hipError_t e = rr::launch_half_sqnorms(xb, dtype, n_rows, dim, out, (hipStream_t)stream);
+  return e == hipSuccess ? RR_OK : hip_fail(e, "rr_half_sqnorms");
 }
 
 int rr_profile_begin(int max_launches) {

@@ -506,7 +506,10 @@ __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& s
   }
 }
 
-template <typename T, int D, bool DENSE, bool NT = false>
+// L2 = true ranks by  q.x - |x|^2/2  (descending == ascending squared L2 distance): the per-row |x|^2/2 of a tile is
+// one more 256-byte LDS-DMA piece (issued by wave 0, ahead of the tile-after-next's pieces so the in-order vmcnt wait of
+// the tile covers it) and the epilogue subtracts it before the filter.
+template <typename T, int D, bool DENSE, bool NT = false, bool L2 = false>
 __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   typedef typename Mfma<T>::frag frag;
   constexpr int KS2 = D / 32;        // 32-wide k slices
@@ -586,24 +589,39 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   const int nb = __builtin_amdgcn_readfirstlane(
       (int)a.nq <= wave * 64 ? 0 : ((int)a.nq - wave * 64 >= 64 ? 4 : ((int)a.nq - wave * 64 + 15) / 16));
 
+  // L2: |x|^2/2 of the 32 rows of tile ordinal jj -> LDS floats [3*TILE_BYTES + slot*256 ...] (lanes 32..63 duplicate)
+  auto issue_norms = [&](uint32_t jj, int slot_) {
+    if (jj >= a.n_tiles) jj = a.n_tiles - 1;
+    uint32_t row = (a.tile_first + jj * a.tile_stride) * kTileRows + (lane & 31);
+    row = row < a.n_rows ? row : a.n_rows - 1;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.half_sqnorm + row),
+                                     (__attribute__((address_space(3))) void*)(smem + 3 * TILE_BYTES + slot_ * 256), 4, 0, 0);
+  };
+  const bool norm_wave = L2 && wave == 0;
+
   uint32_t j = blockIdx.x;
   const uint32_t stride = gridDim.x;
   const uint32_t n_tiles = a.n_tiles;
   if (j < n_tiles) {
     const char* g0 = tile_src(j);
     const char* g1 = tile_src(j + stride);
+    if (norm_wave) issue_norms(j, 0);
 #pragma unroll
     for (int kg = 0; kg < KG; ++kg) issue_piece(g0, 0, kg);
+    if (norm_wave) issue_norms(j + stride, 1);
 #pragma unroll
     for (int kg = 0; kg < KG; ++kg) issue_piece(g1, 1, kg);
   }
   int slot = 0;
   for (; j < n_tiles; j += stride) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KG) : "memory");
+    // queue (oldest first): [norms t] DMA t [norms t+1] DMA t+1 -> all but the youngest KG (+1 on the norm wave) are done
+    if (norm_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KG + 1) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KG) : "memory");
     __builtin_amdgcn_s_barrier();
     int nslot = slot + 2;
     if (nslot >= 3) nslot -= 3;
     const char* gn = tile_src(j + 2 * stride);
+    if (norm_wave) issue_norms(j + 2 * stride, nslot);
 
     // Small batches (the reference issues ONE query per search, data_source.py:114): query blocks past nq do no
     // MFMA work.  nb = this wave's real query blocks: 4 -> full loop, 1..3 -> loop over nb... (1 or 4 compiled),
@@ -652,6 +670,15 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
                        "+v"(acc[1][2]), "+v"(acc[1][3]));
       else
         asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][0]));
+      if (L2) {
+        const f32x4 h0 = *(const f32x4*)(smem + 3 * TILE_BYTES + slot * 256 + (4 * g) * 4);
+        const f32x4 h1 = *(const f32x4*)(smem + 3 * TILE_BYTES + slot * 256 + (16 + 4 * g) * 4);
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+          acc[0][qb] -= h0;
+          acc[1][qb] -= h1;
+        }
+      }
       tile_epilogue16<DENSE, NQB>(a, st, acc, j, lane, wave);
     };
     if (nb >= 2) {
@@ -1175,12 +1202,12 @@ static hipError_t launch_scan_v(const ScanArgs& a, int grid, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <typename T, int D, bool DENSE, bool NT = false>
+template <typename T, int D, bool DENSE, bool NT = false, bool L2 = false>
 static hipError_t launch_scan16(const ScanArgs& a, int grid, hipStream_t st) {
-  const size_t lds = 3 * (size_t)kTileRows * D * 2;
-  hipError_t e = hipFuncSetAttribute((const void*)flat_scan16_kernel<T, D, DENSE, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const size_t lds = 3 * (size_t)kTileRows * D * 2 + (L2 ? 3 * 256 : 0);
+  hipError_t e = hipFuncSetAttribute((const void*)flat_scan16_kernel<T, D, DENSE, NT, L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((flat_scan16_kernel<T, D, DENSE, NT>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((flat_scan16_kernel<T, D, DENSE, NT, L2>), dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
@@ -1199,7 +1226,7 @@ constexpr size_t kNtThresholdBytes = 256ull << 20;
 
 template <typename T, int D>
 static hipError_t launch_scan_t(const ScanArgs& a, bool dense, int grid, hipStream_t st) {
-  if (D == 768 && g_scan_variant != 16) {  // development variants (A/B, diagnostics) exist for the headline dimension only
+  if (D == 768 && g_scan_variant != 16 && !a.half_sqnorm) {  // development variants (A/B, diagnostics) exist for the headline dimension only
     constexpr int DV = 768;
     if (g_scan_variant == 8) return dense ? launch_scan16x8<T, DV, true>(a, grid, st) : launch_scan16x8<T, DV, false>(a, grid, st);
     if (g_scan_variant == 0) return dense ? launch_scan_v<T, DV, true, 0>(a, grid, st) : launch_scan_v<T, DV, false, 0>(a, grid, st);
@@ -1219,8 +1246,12 @@ static hipError_t launch_scan_t(const ScanArgs& a, bool dense, int grid, hipStre
     if (g_scan_variant >= 4) return launch_scan_v<T, DV, true, 1>(a, grid, st);
 #endif
   }
-  if (dense) return launch_scan16<T, D, true, false>(a, grid, st);
   const bool nt = (size_t)a.n_rows * D * 2 > kNtThresholdBytes;
+  if (a.half_sqnorm) {  // L2 metric
+    if (dense) return launch_scan16<T, D, true, false, true>(a, grid, st);
+    return nt ? launch_scan16<T, D, false, true, true>(a, grid, st) : launch_scan16<T, D, false, false, true>(a, grid, st);
+  }
+  if (dense) return launch_scan16<T, D, true, false>(a, grid, st);
   return nt ? launch_scan16<T, D, false, true>(a, grid, st) : launch_scan16<T, D, false, false>(a, grid, st);
 }
 
@@ -1239,6 +1270,7 @@ static hipError_t launch_scan_d(const ScanArgs& a, int D, bool dense, int grid, 
 
 hipError_t launch_flat_scan(const ScanArgs& a, int dtype, int D, bool dense, int grid, hipStream_t st) {
   read_variant_env();
+  if (a.half_sqnorm && (D > kMaxResidentDim || g_scan_variant == 3)) return hipErrorNotSupported;  // L2: resident-query kernel only
   if (scan_queries_per_launch(D) == 128) {  // 768 < D <= 1536: 32 resident queries per wave, half-tile ring
     if (dtype == RR_DTYPE_F16) return launch_scan_half_resident<_Float16>(a, D, dense, grid, st);
     if (dtype == RR_DTYPE_BF16) return launch_scan_half_resident<__bf16>(a, D, dense, grid, st);

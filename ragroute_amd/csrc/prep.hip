@@ -58,6 +58,24 @@ __global__ __launch_bounds__(256) void rows_to_half_kernel(const float* x, int64
   }
 }
 
+// |x|^2 / 2 of every stored (already rounded) row, f32: the L2 metric's per-row term.  One wave per row.
+template <typename T>
+__global__ __launch_bounds__(256) void half_sqnorm_kernel(const T* __restrict__ xb, int64_t n, int dim, float* __restrict__ out) {
+  typedef T vec8 __attribute__((ext_vector_type(8)));
+  const int lane = threadIdx.x & 63;
+  const int64_t wpb = blockDim.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); row < n; row += (int64_t)gridDim.x * wpb) {
+    float acc = 0.f;
+    for (int c = lane; c < dim / 8; c += 64) {
+      const vec8 v = *(const vec8*)(xb + row * dim + c * 8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc += (float)v[i] * (float)v[i];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[row] = 0.5f * acc;
+  }
+}
+
 // Column means of an HBM-resident corpus (the "centroid" the router consumes, reference router.py:147-151; the
 // reference reads it from *_stats.json produced off-tree).  Each thread owns 8 consecutive columns (16-byte loads),
 // a workgroup strides over rows, partial sums meet with float atomics (<= 2048 adds per column).
@@ -107,6 +125,14 @@ static int grid_for_rows(int64_t n) {
   if (g > 8192) g = 8192;
   if (g < 1) g = 1;
   return (int)g;
+}
+
+hipError_t launch_half_sqnorms(const void* xb, int dtype, int64_t n, int dim, float* out, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  if (dtype == RR_DTYPE_F16) hipLaunchKernelGGL(half_sqnorm_kernel<_Float16>, dim3(grid_for_rows(n)), dim3(256), 0, st, (const _Float16*)xb, n, dim, out);
+  else if (dtype == RR_DTYPE_BF16) hipLaunchKernelGGL(half_sqnorm_kernel<__bf16>, dim3(grid_for_rows(n)), dim3(256), 0, st, (const __bf16*)xb, n, dim, out);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
 }
 
 hipError_t launch_l2_normalize_f32(float* x, int64_t n, int64_t d, hipStream_t st) {

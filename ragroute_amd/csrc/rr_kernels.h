@@ -14,6 +14,7 @@ struct ScanArgs {
   uint32_t* cand_cnt;   // [256][grid*2]
   uint64_t* scratch;    // [grid*4][cap] per-wave compaction scratch
   float* dense;         // [256][dense_ld] scores (dense mode)
+  const float* half_sqnorm;  // L2 metric: |x|^2/2 per row, else nullptr
   uint32_t n_rows, nq;
   uint32_t tile_first, tile_stride, n_tiles;  // tile(j) = tile_first + j*tile_stride, j < n_tiles
   uint32_t dense_ld;
@@ -42,7 +43,7 @@ hipError_t launch_init_state(const SelectArgs& a, hipStream_t st);
 hipError_t launch_dense_select(const SelectArgs& a, bool bootstrap, hipStream_t st);
 hipError_t launch_compact(const SelectArgs& a, hipStream_t st);
 hipError_t launch_finalize(const SelectArgs& a, float* D, int64_t* I, int64_t id_offset, const uint8_t* mask, int64_t mask_stride,
-                           hipStream_t st);
+                           const void* xq_l2, int dtype, int dim, hipStream_t st);  // xq_l2 != null: emit squared L2 distances
 hipError_t launch_merge_topk(const float* Din, const int64_t* Iin, int nq, int m, int k, int descending,
                              float* Dout, int64_t* Iout, hipStream_t st);
 
@@ -51,6 +52,7 @@ hipError_t launch_l2_normalize_f32(float* x, int64_t n, int64_t d, hipStream_t s
 hipError_t launch_rows_to_half(const float* x, int64_t n, int64_t d, int64_t ld_in, void* out, int dtype, int64_t d_out,
                                int normalize, hipStream_t st);
 
+hipError_t launch_half_sqnorms(const void* xb, int dtype, int64_t n, int dim, float* out, hipStream_t st);
 hipError_t launch_centroid(const void* xb, int dtype, int64_t n, int dim, int d, float* out, hipStream_t st);
 
 // router.hip

@@ -227,16 +227,34 @@ __global__ __launch_bounds__(1024) void compact_kernel(SelectArgs a) {
   }
 }
 
-__global__ void finalize_kernel(SelectArgs a, float* D, int64_t* I, int64_t id_offset, const uint8_t* mask, int64_t mask_stride) {
+// L2 = the list holds q.x - |x|^2/2; the reported distance is |q|^2 - 2 * that (squared L2, as faiss.IndexFlatL2), padding +inf.
+template <typename T, bool L2>
+__global__ __launch_bounds__(256) void finalize_kernel(SelectArgs a, float* D, int64_t* I, int64_t id_offset, const uint8_t* mask,
+                                                       int64_t mask_stride, const T* xq, int dim) {
+  __shared__ float red[4];
   const uint32_t q = blockIdx.x;
   if (q >= a.nq) return;
+  float qn = 0.f;
+  if (L2) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) {
+      const float v = (float)xq[(size_t)q * dim + i];
+      acc += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    qn = (red[0] + red[1]) + (red[2] + red[3]);
+  }
   const int cnt = (mask && !mask[(size_t)q * mask_stride]) ? 0 : (int)a.list_cnt[q];
   for (int i = threadIdx.x; i < a.k; i += blockDim.x) {
-    float s = -__builtin_inff();
+    float s = L2 ? __builtin_inff() : -__builtin_inff();
     int64_t id = -1;
     if (i < cnt) {
       const uint64_t key = a.list[(size_t)q * a.list_ld + i];
       s = key_score(key);
+      if (L2) s = qn - 2.f * s;
       id = (int64_t)key_id(key) + id_offset;
     }
     D[(size_t)q * a.k + i] = s;
@@ -312,8 +330,16 @@ hipError_t launch_compact(const SelectArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t launch_finalize(const SelectArgs& a, float* D, int64_t* I, int64_t id_offset, const uint8_t* mask, int64_t mask_stride,
-                           hipStream_t st) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(kQueriesPerBlock), dim3(256), 0, st, a, D, I, id_offset, mask, mask_stride);
+                           const void* xq_l2, int dtype, int dim, hipStream_t st) {
+  if (!xq_l2)
+    hipLaunchKernelGGL((finalize_kernel<_Float16, false>), dim3(kQueriesPerBlock), dim3(256), 0, st, a, D, I, id_offset, mask, mask_stride,
+                       (const _Float16*)nullptr, dim);
+  else if (dtype == RR_DTYPE_F16)
+    hipLaunchKernelGGL((finalize_kernel<_Float16, true>), dim3(kQueriesPerBlock), dim3(256), 0, st, a, D, I, id_offset, mask, mask_stride,
+                       (const _Float16*)xq_l2, dim);
+  else
+    hipLaunchKernelGGL((finalize_kernel<__bf16, true>), dim3(kQueriesPerBlock), dim3(256), 0, st, a, D, I, id_offset, mask, mask_stride,
+                       (const __bf16*)xq_l2, dim);
   return hipGetLastError();
 }
 hipError_t launch_merge_topk(const float* Din, const int64_t* Iin, int nq, int m, int k, int descending, float* Dout,

@@ -45,13 +45,14 @@ def normalize_L2(x):
 class FlatIndex:
     """Exact inner-product index (the role of faiss.IndexFlatIP in the reference).
 
-    metric: "ip" (reference behaviour) or "cosine" (rows and queries L2-normalised on ingest/search,
-    i.e. normalize_L2 + IP as data_source.py:196-203 does for the wikipedia corpora).
+    metric: "ip" (reference behaviour), "cosine" (rows and queries L2-normalised on ingest/search, i.e. normalize_L2 + IP
+    as data_source.py:196-203 does for the wikipedia corpora) or "l2" (squared L2 distances, nearest first: the role of
+    faiss.IndexFlatL2; d <= 768).
     dtype : "fp16" or "bf16" storage/MFMA input type; scores accumulate in f32.
     """
 
     def __init__(self, d, metric="ip", dtype="fp16", device=None):
-        if metric not in ("ip", "cosine"):
+        if metric not in ("ip", "cosine", "l2"):
             raise ValueError(f"unknown metric {metric!r}")
         if dtype not in _TORCH_DTYPE:
             raise ValueError(f"unknown dtype {dtype!r}")
@@ -65,6 +66,9 @@ class FlatIndex:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.ntotal = 0
         self._xb = torch.empty((0, self.dim), dtype=_TORCH_DTYPE[dtype], device=self.device)
+        self._hn = None  # |x|^2/2 per row (metric "l2")
+        if metric == "l2" and self.dim > 768:
+            raise _lib.RagrouteHipError("the L2 metric supports d <= 768 in this build")
         self._ws = {}
 
     # -- storage -----------------------------------------------------------------------------
@@ -93,6 +97,15 @@ class FlatIndex:
                                             self.dim, int(self.metric == "cosine"), _stream_ptr()), "rr_rows_to_half")
                 del part
         self.ntotal += n
+        self._refresh_norms()
+
+    def _refresh_norms(self):
+        if self.metric != "l2":
+            return
+        self._hn = torch.empty(max(1, self.ntotal), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().rr_half_sqnorms(self._xb.data_ptr(), _RR_DTYPE[self.dtype], self.ntotal, self.dim, self._hn.data_ptr(),
+                                        _stream_ptr()), "rr_half_sqnorms")
 
     def adopt(self, xb_dev, ntotal=None):
         """Use an existing device matrix [n, dim] of the index dtype as the corpus (no copy)."""
@@ -100,6 +113,7 @@ class FlatIndex:
             raise ValueError("adopt() needs a contiguous device matrix [n, rr_padded_dim(d)] of the index dtype")
         self._xb = xb_dev
         self.ntotal = int(xb_dev.shape[0] if ntotal is None else ntotal)
+        self._refresh_norms()
 
     def centroid(self):
         """float32 CUDA vector [d]: mean of the stored rows (the router's centroid feature, router.py:147-151)."""
@@ -154,9 +168,15 @@ class FlatIndex:
             if route_mask.dtype not in (torch.bool, torch.uint8) or route_mask.dim() != 1 or route_mask.shape[0] != nq or not route_mask.is_cuda:
                 raise ValueError("route_mask must be a bool/uint8 CUDA vector with one entry per query")
             mptr, mstride = route_mask.data_ptr(), route_mask.stride(0)
-        check(lib().rr_flat_search(self._xb.data_ptr(), _RR_DTYPE[self.dtype], self.ntotal, self.dim, xq_half.data_ptr(), nq, k,
-                                   D.data_ptr(), I.data_ptr(), id_offset, ws.data_ptr(), ws.numel(), mptr, mstride, _stream_ptr()),
-              "rr_flat_search")
+        if self.metric == "l2":
+            check(lib().rr_flat_search_l2(self._xb.data_ptr(), self._hn.data_ptr() if self._hn is not None else None,
+                                          _RR_DTYPE[self.dtype], self.ntotal, self.dim, xq_half.data_ptr(), nq, k, D.data_ptr(),
+                                          I.data_ptr(), id_offset, ws.data_ptr(), ws.numel(), mptr, mstride, _stream_ptr()),
+                  "rr_flat_search_l2")
+        else:
+            check(lib().rr_flat_search(self._xb.data_ptr(), _RR_DTYPE[self.dtype], self.ntotal, self.dim, xq_half.data_ptr(), nq, k,
+                                       D.data_ptr(), I.data_ptr(), id_offset, ws.data_ptr(), ws.numel(), mptr, mstride, _stream_ptr()),
+                  "rr_flat_search")
         return D, I
 
     def search(self, xq, k):

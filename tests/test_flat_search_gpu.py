@@ -183,3 +183,26 @@ def test_randomised_shapes(gpu):
         Dref, Iref = O.flat_search_ip(xb.reshape(n, d), xq, k)
         assert np.array_equal(I, Iref), (it, n, d, nq, k, dtype)
         assert np.array_equal(D, Dref), (it, n, d, nq, k, dtype)
+
+
+@pytest.mark.parametrize("n,nq,k,d", [(5000, 40, 10, 768), (90_000, 256, 32, 768), (30_000, 7, 100, 200), (33, 3, 50, 128)])
+def test_l2_metric_bit_exact_on_integer_data(gpu, n, nq, k, d):
+    """Squared-L2 flat search (faiss.IndexFlatL2 contract): nearest first, ties by ascending id, (+inf,-1) padding."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(n + k)
+    xb, xq = int_data(rng, n, d, -2, 3), int_data(rng, nq, d, -2, 3)
+    D, I = _index(gpu, xb, d, metric="l2").search(xq, k)
+    Dref, Iref = O.flat_search_l2(xb, xq, k)
+    assert np.array_equal(I, Iref) and np.array_equal(D, Dref)
+
+
+def test_l2_metric_gaussian(gpu):
+    from oracle import oracle as O
+    rng = np.random.default_rng(12)
+    n, nq, d, k = 100_000, 16, 768, 10
+    xb = half_round(rng.standard_normal((n, d)).astype(np.float32))
+    xq = half_round(rng.standard_normal((nq, d)).astype(np.float32))
+    D, I = _index(gpu, xb, d, metric="l2").search(xq, k)
+    Dref, Iref = O.flat_search_l2(xb, xq, k)
+    assert np.allclose(D, Dref, rtol=2e-5, atol=2e-2)
+    assert np.mean([len(set(I[q]) & set(Iref[q])) / k for q in range(nq)]) >= 0.99
