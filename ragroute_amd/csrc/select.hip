@@ -51,33 +51,16 @@ __global__ void init_state_kernel(SelectArgs a) {
   }
 }
 
-// Bootstrap threshold: the k-th largest score of the dense sample row, by a 4-pass 8-bit radix select over the
-// 32-bit order keys (LDS histograms).  Only the score matters here (ties and ids are irrelevant for a lower bound).
-__global__ __launch_bounds__(1024) void bootstrap_select_kernel(SelectArgs a) {
-  __shared__ uint32_t hist[256];
-  __shared__ uint32_t sel_prefix, sel_k;
-  const uint32_t q = blockIdx.x;
-  if (q >= a.nq) return;
-  const int n = (int)a.dense_cols;
-  constexpr int PER = kSelectCap / 1024;  // keys per thread
-  uint32_t key[PER];
-#pragma unroll
-  for (int e = 0; e < PER; ++e) {
-    const int c = threadIdx.x + e * 1024;
-    uint32_t o = 0;
-    if (c < n) {
-      const uint32_t row = (a.tile_first + (uint32_t)(c >> 5) * a.tile_stride) * kTileRows + (c & 31);
-      const float s = a.dense[(size_t)q * a.dense_ld + c];
-      if (row < a.n_rows) o = ord_f32(s);  // NaN -> 0
-    }
-    key[e] = o;
-  }
-  if (threadIdx.x == 0) { sel_prefix = 0; sel_k = (uint32_t)a.k; }
+// k-th largest 32-bit order key among the keys a 1024-thread workgroup holds in registers (PER each), by a 4-pass 8-bit
+// radix select over LDS histograms.  Returns the key (0 if fewer than k non-zero keys exist).
+template <int PER>
+__device__ uint32_t radix_select_kth(const uint32_t (&key)[PER], uint32_t k, uint32_t* hist /*[256]*/, uint32_t* sel /*[2]*/) {
+  if (threadIdx.x == 0) { sel[0] = 0; sel[1] = k; }
   uint32_t mask = 0;
   for (int shift = 24; shift >= 0; shift -= 8) {
     if (threadIdx.x < 256) hist[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t prefix = sel_prefix;
+    const uint32_t prefix = sel[0];
 #pragma unroll
     for (int e = 0; e < PER; ++e)
       if ((key[e] & mask) == prefix) atomicAdd(&hist[(key[e] >> shift) & 255], 1u);
@@ -85,62 +68,82 @@ __global__ __launch_bounds__(1024) void bootstrap_select_kernel(SelectArgs a) {
     if (threadIdx.x < 64) {  // one wave: suffix sums over the 256 bins (4 bins per lane), find the bin holding the k-th
       const int l = threadIdx.x;
       const uint32_t h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
-      uint32_t above = h0 + h1 + h2 + h3;  // becomes: count in lanes strictly above this one
-      uint32_t incl = above;
+      uint32_t incl = h0 + h1 + h2 + h3;
+      const uint32_t own = incl;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const uint32_t v = __shfl_down(incl, o, 64);
         if (l + o < 64) incl += v;
       }
-      above = incl - above;
-      const uint32_t kk = sel_k;
-      // bins of this lane from high to low: 4l+3, 4l+2, 4l+1, 4l
-      uint32_t c3 = above + h3, c2 = c3 + h2, c1 = c2 + h1, c0 = c1 + h0;
-      int bin = -1; uint32_t before = 0;
+      const uint32_t above = incl - own;  // keys in bins of higher lanes
+      const uint32_t kk = sel[1];
+      const uint32_t c3 = above + h3, c2 = c3 + h2, c1 = c2 + h1, c0 = c1 + h0;
       if (above < kk && kk <= c0) {
+        int bin; uint32_t before;
         if (kk <= c3) { bin = 4 * l + 3; before = above; }
         else if (kk <= c2) { bin = 4 * l + 2; before = c3; }
         else if (kk <= c1) { bin = 4 * l + 1; before = c2; }
         else { bin = 4 * l; before = c1; }
-        sel_prefix = prefix | ((uint32_t)bin << shift);
-        sel_k = kk - before;
+        sel[0] = prefix | ((uint32_t)bin << shift);
+        sel[1] = kk - before;
       }
     }
     mask |= 0xFFu << shift;
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    const uint32_t kth = sel_prefix;  // ord key of the k-th largest sample score (0 if fewer than k valid rows)
-    if (kth != 0 && a.k <= n) a.thr[q] = next_below(unord_f32(kth));
-  }
+  return sel[0];
 }
 
-// Tiny corpora: full sort of the dense row, the k best go straight to the running list.
+// Selection over one dense score row per query (<= 8192 columns).
+//  BOOTSTRAP: only the k-th largest score matters (a lower bound of the final k-th best); thr = next_below(it).
+//  otherwise (tiny corpora): radix-select the k-th score, gather the keys at or above it (k plus ties), sort that
+//  handful by (score desc, id asc) and write the k best to the running list.
+template <bool BOOTSTRAP>
 __global__ __launch_bounds__(1024) void dense_select_kernel(SelectArgs a) {
   __shared__ uint64_t keys[kSelectCap];
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sel[2];
+  __shared__ int fill_s;
   const uint32_t q = blockIdx.x;
   if (q >= a.nq) return;
   const int n = (int)a.dense_cols;
-  const int np = pow2_ceil(n < 2 ? 2 : n);
-  for (int c = threadIdx.x; c < np; c += blockDim.x) {
-    uint64_t key = 0;
+  constexpr int PER = kSelectCap / 1024;
+  uint32_t ordk[PER], ids[PER];
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    const int c = threadIdx.x + e * 1024;
+    uint32_t o = 0, row = 0;
     if (c < n) {
-      const uint32_t row = (a.tile_first + (uint32_t)(c >> 5) * a.tile_stride) * kTileRows + (c & 31);
+      row = (a.tile_first + (uint32_t)(c >> 5) * a.tile_stride) * kTileRows + (c & 31);
       const float s = a.dense[(size_t)q * a.dense_ld + c];
-      if (row < a.n_rows && s == s) key = make_key(s, row);
+      if (row < a.n_rows) o = ord_f32(s);  // NaN -> 0 = absent
     }
-    keys[c] = key;
+    ordk[e] = o;
+    ids[e] = row;
+  }
+  if (threadIdx.x == 0) fill_s = 0;
+  const uint32_t kth = radix_select_kth<PER>(ordk, (uint32_t)a.k, hist, sel);  // ends with a barrier
+  if (BOOTSTRAP) {
+    if (threadIdx.x == 0 && kth != 0 && a.k <= n) a.thr[q] = next_below(unord_f32(kth));
+    return;
+  }
+  // kth == 0: fewer than k valid rows -> keep every valid one
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    if (ordk[e] != 0 && ordk[e] >= kth) {
+      const int pos = atomicAdd(&fill_s, 1);
+      keys[pos] = ((uint64_t)ordk[e] << 32) | (uint64_t)(0xFFFFFFFFu - ids[e]);
+    }
   }
   __syncthreads();
+  const int fill = fill_s;
+  const int np = pow2_ceil(fill < 2 ? 2 : fill);
+  for (int i = fill + threadIdx.x; i < np; i += blockDim.x) keys[i] = 0;
+  __syncthreads();
   bitonic_sort_desc(keys, np);
-  for (int i = threadIdx.x; i < a.k; i += blockDim.x) {
-    const uint64_t key = i < np ? keys[i] : 0;
-    a.list[(size_t)q * a.list_ld + i] = key;
-    // the first empty slot (or k) is the count
-    const bool valid = (key >> 32) != 0;
-    const bool next_valid = (i + 1 < a.k) && (i + 1 < np) && ((keys[i + 1] >> 32) != 0);
-    if (valid && !next_valid) a.list_cnt[q] = i + 1;
-  }
+  const int cnt = fill < a.k ? fill : a.k;
+  for (int i = threadIdx.x; i < a.k; i += blockDim.x) a.list[(size_t)q * a.list_ld + i] = i < cnt ? keys[i] : 0;
+  if (threadIdx.x == 0) a.list_cnt[q] = cnt;
 }
 
 __global__ __launch_bounds__(1024) void compact_kernel(SelectArgs a) {
@@ -321,8 +324,8 @@ hipError_t launch_init_state(const SelectArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t launch_dense_select(const SelectArgs& a, bool bootstrap, hipStream_t st) {
-  if (bootstrap) hipLaunchKernelGGL(bootstrap_select_kernel, dim3(kQueriesPerBlock), dim3(1024), 0, st, a);
-  else hipLaunchKernelGGL(dense_select_kernel, dim3(kQueriesPerBlock), dim3(1024), 0, st, a);
+  if (bootstrap) hipLaunchKernelGGL(dense_select_kernel<true>, dim3(kQueriesPerBlock), dim3(1024), 0, st, a);
+  else hipLaunchKernelGGL(dense_select_kernel<false>, dim3(kQueriesPerBlock), dim3(1024), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_compact(const SelectArgs& a, hipStream_t st) {
