@@ -17,6 +17,15 @@
 //    to its k best and raises that lane's threshold.  Nothing is ever dropped that could be in
 //    the final top-k (see DESIGN.md "exactness").
 //  * DENSE=true writes every score instead (bootstrap sample and tiny corpora).
+//
+// Kernels in this file (launch_flat_scan picks one; RR_SCAN_VARIANT overrides for A/B runs at D = 768):
+//   flat_scan16_kernel      default, D <= 768: 16x16x32 MFMA, hand-pipelined asm loop, nt LDS-DMA, optional L2 metric
+//   flat_scan16h_kernel     768 < D <= 1536: 32 resident queries per wave, half-tile LDS ring (128 queries per launch)
+//   flat_scan_generic_kernel  D <= 8192 (multiples of 64): queries re-streamed from L2, compiler-scheduled  (variant 3)
+//   flat_scan_kernel        the same design on the 32x32x16 shape: variant 1 (asm loop, 6.7 % slower: lower clock),
+//                           variant 0 (compiler-scheduled builtin MFMA, the first version), variant 2 (stamped
+//                           diagnostic), 4..9 / 48 timing-only ablations (-DRR_ABLATION_VARIANTS)
+//   flat_scan16x8_kernel    variant 8: two waves per SIMD, 32 queries per wave (11 % slower; kept as a measured negative)
 #include <stdlib.h>
 
 #include <type_traits>

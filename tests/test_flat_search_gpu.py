@@ -206,3 +206,17 @@ def test_l2_metric_gaussian(gpu):
     Dref, Iref = O.flat_search_l2(xb, xq, k)
     assert np.allclose(D, Dref, rtol=2e-5, atol=2e-2)
     assert np.mean([len(set(I[q]) & set(Iref[q])) / k for q in range(nq)]) >= 0.99
+
+
+def test_nan_rows_are_never_selected(gpu):
+    """A row whose score is NaN is absent from every result (oracle and GPU agree), through the dense path and the chunks."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(77)
+    for n in (3000, 40_000):
+        xb, xq = int_data(rng, n, 768), int_data(rng, 5, 768)
+        bad = rng.choice(n, size=20, replace=False)
+        xb[bad, 3] = np.nan
+        D, I = _index(gpu, xb, 768).search(xq, 32)
+        Dref, Iref = O.flat_search_ip(xb, xq, 32)
+        assert not np.isin(I, bad).any()
+        assert np.array_equal(I, Iref) and np.array_equal(D, Dref)
