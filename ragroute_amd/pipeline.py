@@ -30,7 +30,11 @@ class RetrievalPipeline:
         return self.router.run(xq_models)
 
     def search(self, xq, k, xq_models=None):
-        """xq: f32 CUDA [B, d] query embeddings for the shards; xq_models: router input (defaults to xq as the single model)."""
+        """xq: f32 CUDA [B, d] query embeddings for the shards, or a dict {shard_id: [B, d_shard]} when sources use
+        different encoders (FeB4RAG: 768 / 1024 / 4096 wide, config.py:44-58, http_server.py:201-209 picks the embedding of
+        each source's model); xq_models: router input [B, n_models, d_max] (defaults to xq as the single model)."""
+        if isinstance(xq, dict):
+            return self._search_per_shard(xq, k, xq_models)
         _, mask = self.route(xq[:, None, :].contiguous() if xq_models is None else xq_models)
         B = xq.shape[0]
         if len(self.shards) == 1:
@@ -46,6 +50,18 @@ class RetrievalPipeline:
             return merge_topk(Dg, Ig, k, True)
         Ds, Is = [], []
         for idx, sid in zip(self.shards, self.shard_ids):
+            D, I = idx.search_prepared(idx.prepare_queries(xq), k, id_offset=sid << SHARD_SHIFT,
+                                       route_mask=None if mask is None else mask[:, sid])
+            Ds.append(D)
+            Is.append(I)
+        Dg, Ig = gather_candidates(torch.cat(Ds, 1), torch.cat(Is, 1), self.group)
+        return merge_topk(Dg, Ig, k, True)
+
+    def _search_per_shard(self, xq_by_shard, k, xq_models):
+        _, mask = (None, None) if xq_models is None else self.route(xq_models)
+        Ds, Is = [], []
+        for idx, sid in zip(self.shards, self.shard_ids):
+            xq = xq_by_shard[sid]
             D, I = idx.search_prepared(idx.prepare_queries(xq), k, id_offset=sid << SHARD_SHIFT,
                                        route_mask=None if mask is None else mask[:, sid])
             Ds.append(D)

@@ -232,7 +232,7 @@ def test_pipeline_route_search_merge(gpu):
         idx = FlatIndex(768, device=gpu)
         idx.add(p)
         shards.append(idx)
-    xq = int_data(rng, 24, 768)
+    xq = int_data(rng, 256, 768)   # BASELINE config 3: medrag, 4 corpora on one GPU + router forward, query batch 256
     r._fold()
     pipe = RetrievalPipeline(shards, [0, 1, 2, 3], router=r._folded)
     xt = torch.from_numpy(xq).to(gpu)
@@ -241,7 +241,7 @@ def test_pipeline_route_search_merge(gpu):
     mask = mask.cpu().numpy()
     assert mask.any() and not mask.all()
     D, I = D.cpu().numpy(), I.cpu().numpy()
-    for q in range(24):
+    for q in range(0, 256, 5):
         sel = [s for s in range(4) if mask[q, s]]
         if not sel:
             assert (I[q] == -1).all()
@@ -250,3 +250,30 @@ def test_pipeline_route_search_merge(gpu):
         gids = np.concatenate([np.arange(len(parts[s])) + (s << SHARD_SHIFT) for s in sel])
         Dr, Ir = O.flat_search_ip(cat, xq[q:q + 1], 32)
         assert np.array_equal(D[q], Dr[0]) and np.array_equal(I[q], gids[Ir[0]])
+
+
+def test_pipeline_mixed_encoders_feb4rag_shapes(gpu):
+    """FeB4RAG-like federation (BASELINE config 4 on one rank): sources of different embedding widths (768 / 1024 / 4096), each
+    searched with its own encoder's query embedding, merged into one top-10 by score (k = 10, config.py:99)."""
+    from oracle import oracle as O
+    from ragroute_amd.flat_index import FlatIndex
+    from ragroute_amd.pipeline import RetrievalPipeline
+    from ragroute_amd.sharded import SHARD_SHIFT
+    rng = np.random.default_rng(6)
+    dims, sizes = [768, 1024, 4096, 1024], [12_000, 9_000, 3_000, 20_500]
+    parts = [int_data(rng, n, d, -1, 2) for n, d in zip(sizes, dims)]
+    queries = {s: int_data(rng, 33, d, -1, 2) for s, d in enumerate(dims)}
+    shards = []
+    for p_, d in zip(parts, dims):
+        idx = FlatIndex(d, device=gpu)
+        idx.add(p_)
+        shards.append(idx)
+    pipe = RetrievalPipeline(shards, [0, 1, 2, 3])
+    D, I = pipe.search({s: torch.from_numpy(q).to(gpu) for s, q in queries.items()}, 10)
+    cand_D, cand_I = [], []
+    for s in range(4):
+        Ds, Is = O.flat_search_ip(parts[s], queries[s], 10)
+        cand_D.append(Ds)
+        cand_I.append(Is + (s << SHARD_SHIFT))
+    Dr, Ir = O.merge_topk(np.concatenate(cand_D, 1), np.concatenate(cand_I, 1), 10, True)
+    assert np.array_equal(D.cpu().numpy(), Dr) and np.array_equal(I.cpu().numpy(), Ir)
