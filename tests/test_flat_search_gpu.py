@@ -220,3 +220,14 @@ def test_nan_rows_are_never_selected(gpu):
         Dref, Iref = O.flat_search_ip(xb, xq, 32)
         assert not np.isin(I, bad).any()
         assert np.array_equal(I, Iref) and np.array_equal(D, Dref)
+
+
+@pytest.mark.parametrize("k", [500, 1024])
+def test_large_k(gpu, k):
+    """k up to RR_MAX_K = 1024 (FAISS-GPU's own limit is 2048): bigger candidate buffers, same exact result."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(k)
+    xb, xq = int_data(rng, 30_000, 256), int_data(rng, 6, 256)
+    D, I = _index(gpu, xb, 256).search(xq, k)
+    Dref, Iref = O.flat_search_ip(xb, xq, k)
+    assert np.array_equal(I, Iref) and np.array_equal(D, Dref)
