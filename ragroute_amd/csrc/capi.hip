@@ -53,13 +53,14 @@ hipError_t profiled_scan(const rr::ScanArgs& a, int dtype, int D, bool dense, in
 }
 
 // Schedule knobs (defaults from rr_common.h; RR_SAMPLE_ROWS / RR_CHUNK_GROWTH override them for tuning runs)
-int g_sample_rows = rr::kSampleRows, g_chunk_growth = rr::kChunkGrowth;
+int g_sample_rows = rr::kSampleRows, g_chunk_growth = rr::kChunkGrowth, g_dynamic_tiles = 0;  // RR_DYNAMIC_TILES=1: ticketed tiles (no gain: see DESIGN.md)
 void read_schedule_env() {
   static const bool once = [] {
     if (const char* v = getenv("RR_SAMPLE_ROWS")) {
       int r = atoi(v) / rr::kTileRows * rr::kTileRows;
       if (r >= 1024 && r <= rr::kSampleRows) g_sample_rows = r;
     }
+    if (const char* v = getenv("RR_DYNAMIC_TILES")) g_dynamic_tiles = atoi(v);
     if (const char* v = getenv("RR_CHUNK_GROWTH")) {
       int g = atoi(v);
       if (g >= 2 && g <= 1024) g_chunk_growth = g;
@@ -74,6 +75,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct Workspace {
   float* thr;
   uint32_t* list_cnt;
+  uint32_t* tile_counters;
   uint64_t* list;
   uint32_t* cand_cnt;
   uint64_t* scratch;
@@ -90,6 +92,7 @@ Workspace carve(char* base, int k, int grid) {
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return base ? base + o : (char*)nullptr; };
   w.thr = (float*)take(kQueriesPerBlock * sizeof(float));
   w.list_cnt = (uint32_t*)take(kQueriesPerBlock * sizeof(uint32_t));
+  w.tile_counters = (uint32_t*)take(16 * 64);  // one 64-byte line per scan launch of a search
   w.list = (uint64_t*)take((size_t)kQueriesPerBlock * kMaxK * sizeof(uint64_t));
   w.cand_cnt = (uint32_t*)take((size_t)kQueriesPerBlock * grid * 4 * sizeof(uint32_t));
   w.scratch = (uint64_t*)take((size_t)grid * 8 * cap * sizeof(uint64_t));  // up to 2 workgroups per CU x 4 waves
@@ -178,7 +181,7 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
 
     SelectArgs s;
     memset(&s, 0, sizeof(s));
-    s.thr = w.thr; s.list = w.list; s.list_cnt = w.list_cnt; s.cand = w.cand; s.cand_cnt = w.cand_cnt;
+    s.thr = w.thr; s.list = w.list; s.list_cnt = w.list_cnt; s.tile_counters = w.tile_counters; s.cand = w.cand; s.cand_cnt = w.cand_cnt;
     s.dense = w.dense; s.dense_ld = kSampleRows; s.n_rows = (uint32_t)n_rows; s.nq = (uint32_t)nqb;
     s.nbuf = (uint32_t)grid * (uint32_t)scan_bufs_per_wg(dim); s.list_ld = kMaxK; s.cap = cap; s.k = k;
     ScanArgs a;
@@ -203,9 +206,13 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
       RR_CHECK(launch_dense_select(s, true, st), "rr_flat_search/bootstrap_select");
       // chunks [0,e1), [e1,e2), ... with e growing 8x: ~7k survivors per query and chunk
       uint64_t begin = 0, end = (uint64_t)n_sample_tiles * g_chunk_growth;  // in tiles
+      int launch_no = 0;
       while (begin < total_tiles) {
         if (end > total_tiles) end = total_tiles;
         a.tile_first = (uint32_t)begin; a.tile_stride = 1; a.n_tiles = (uint32_t)(end - begin);
+        a.tile_counter = (g_dynamic_tiles && launch_no < 16) ? w.tile_counters + 16 * launch_no : nullptr;
+        ++launch_no;
+        a.timeline = getenv("RR_SCAN_TIMELINE") ? (uint64_t*)w.dense : nullptr;  // the dense buffer is idle during chunk scans
         RR_CHECK(profiled_scan(a, dtype, dim, false, grid, st), "rr_flat_search/scan");
         RR_CHECK(launch_compact(s, st), "rr_flat_search/compact");
         begin = end;

@@ -446,6 +446,8 @@ RR_MFMA16(_Float16, "v_mfma_f32_16x16x32_f16", f16x8)
 RR_MFMA16(__bf16, "v_mfma_f32_16x16x32_bf16", bf16x8)
 #undef RR_MFMA16
 
+constexpr int kTicketBatch = 4;  // tiles per dynamic ticket
+
 struct LaneState4 {
   float thr[4];
   uint32_t cnt[4], off[4];
@@ -532,6 +534,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 15, g = lane >> 4;
+  if (a.timeline && threadIdx.x == 0) a.timeline[blockIdx.x] = __builtin_amdgcn_s_memrealtime();  // diagnostics only
 
   // ---- resident queries: B fragment (qb, s2): query wave*64 + qb*16 + col, k = 32 s2 + 8 g .. +7 -------------
   frag q[4][KS2];
@@ -606,35 +609,77 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.half_sqnorm + row),
                                      (__attribute__((address_space(3))) void*)(smem + 3 * TILE_BYTES + slot_ * 256), 4, 0, 0);
   };
-  const bool norm_wave = L2 && wave == 0;
+  const bool norm_wave = L2 && wave == 1;  // not the ticket wave (wave 0)
 
-  uint32_t j = blockIdx.x;
+  // Tile schedule.  Static: ordinals blockIdx, +grid, +2 grid, ...  Dynamic (a.tile_counter): the first two ordinals are
+  // static, later ones come in batches of kTicketBatch consecutive ordinals 2*grid + atomicAdd(counter, kTicketBatch)
+  // (one dequeue per tile from 256 workgroups would exceed what a single counter word sustains, ~88 per us): XCDs run at different speeds (measured 7.5 % apart
+  // under load) and a static split makes every launch wait for the slowest one.  Wave 0 requests the ticket ONE tile
+  // ahead with an asm returning atomic that sits in the in-order vmcnt queue before that tile's DMA pieces, so the
+  // tile's own vmcnt wait covers it; lane 0 posts it to LDS before the barrier, every wave reads it after.
   const uint32_t stride = gridDim.x;
   const uint32_t n_tiles = a.n_tiles;
+  const bool dyn = a.tile_counter != nullptr;
+  uint32_t* ticket_lds = (uint32_t*)(smem + 3 * TILE_BYTES + 3 * 256);  // 2 alternating words
+  // The atomic returns asynchronously, so its destination must not be a compiler-visible value (hipcc copies such a
+  // register right after the asm statement, before the data lands - seen in the ISA).  It returns into the hard-wired
+  // accumulator register a255, claimed through clobbers, and is read inside the same asm statement as the covering vmcnt.
+  // A returning atomic is not guaranteed to complete in order with the LDS-DMA loads of the vmcnt queue, so no counted
+  // wait can cover it: a255 is pre-loaded with a sentinel and polled at consume time until the return has landed
+  // (normally zero spins: the request is a whole tile old).
+  const uint32_t one = kTicketBatch, sentinel = 0xFFFFFFFFu;  // a ticket = kTicketBatch consecutive tile ordinals
+  auto request_ticket = [&]() {
+    if (dyn && wave == 0 && lane == 0)  // ONE lane: every active lane would add to the counter
+      // VMEM atomics share one acc bit for data and destination: the addend lives in a254
+      asm volatile("v_accvgpr_write_b32 a254, %1\n\tv_accvgpr_write_b32 a255, %2\n\ts_nop 1\n\tglobal_atomic_add a255, %0, a254, off sc0"
+                   ::"v"(a.tile_counter), "v"(one), "v"(sentinel) : "memory", "a254", "a255");
+  };
+  uint32_t j = blockIdx.x, j1 = blockIdx.x + stride;
+  request_ticket();
   if (j < n_tiles) {
     const char* g0 = tile_src(j);
-    const char* g1 = tile_src(j + stride);
+    const char* g1 = tile_src(j1);
     if (norm_wave) issue_norms(j, 0);
 #pragma unroll
     for (int kg = 0; kg < KG; ++kg) issue_piece(g0, 0, kg);
-    if (norm_wave) issue_norms(j + stride, 1);
+    if (norm_wave) issue_norms(j1, 1);
 #pragma unroll
     for (int kg = 0; kg < KG; ++kg) issue_piece(g1, 1, kg);
   }
-  int slot = 0;
-  for (; j < n_tiles; j += stride) {
-    // queue (oldest first): [norms t] DMA t [norms t+1] DMA t+1 -> all but the youngest KG (+1 on the norm wave) are done
+  int slot = 0, par = 0, sub = kTicketBatch;
+  uint32_t base = 0, dbg_iter = 0;
+  while (j < n_tiles) {
+    // queue (oldest first): [norms t] DMA t  ticket [norms t+1] DMA t+1 -> all but the youngest KG (+1 on the norm wave) are done
     if (norm_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KG + 1) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KG) : "memory");
+    const bool fetch = dyn && sub == kTicketBatch;  // workgroup-uniform: a new batch of kTicketBatch consecutive tiles starts
+    if (fetch && wave == 0) {
+      uint32_t ticket;
+      do {
+        uint32_t tk;
+        asm volatile("v_accvgpr_read_b32 %0, a255" : "=v"(tk)::"a255");
+        ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+      } while (ticket == sentinel);
+      if (lane == 0) ticket_lds[par] = 2 * stride + ticket;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // a raw s_barrier does not wait for the LDS store
+    }
+    if (a.timeline && threadIdx.x == 0) a.timeline[3 * gridDim.x + blockIdx.x * 64 + (dbg_iter++ & 63)] = j;  // diagnostics only
     __builtin_amdgcn_s_barrier();
     int nslot = slot + 2;
     if (nslot >= 3) nslot -= 3;
-    const char* gn = tile_src(j + 2 * stride);
-    if (norm_wave) issue_norms(j + 2 * stride, nslot);
-
-    // Small batches (the reference issues ONE query per search, data_source.py:114): query blocks past nq do no
-    // MFMA work.  nb = this wave's real query blocks: 4 -> full loop, 1..3 -> loop over nb... (1 or 4 compiled),
-    // 0 -> the wave only feeds the DMA ring and the barrier, so a 1-query search runs HBM-bound.
+    uint32_t j2 = j1 + stride;
+    if (dyn) {
+      if (fetch) {
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket_lds[par]);
+        par ^= 1;
+        sub = 0;
+        request_ticket();  // the next batch: kTicketBatch tiles of lead time, issued before this tile's norms / DMA pieces
+      }
+      j2 = base + sub;
+      ++sub;
+    }
+    const char* gn = tile_src(j2);
+    if (norm_wave) issue_norms(j2, nslot);
     auto compute = [&](auto tag) {
       constexpr int NQB = decltype(tag)::value;
       f32x4 acc[2][4];
@@ -700,11 +745,17 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
     }
     slot = slot + 1;
     if (slot >= 3) slot = 0;
+    j = j1;
+    j1 = j2;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory", "a255");  // no LDS-DMA (or ticket) may outlive the workgroup
   if (!DENSE) {
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) a.cand_cnt[(wave * 64 + qb * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
+  }
+  if (a.timeline && threadIdx.x == 0) {
+    a.timeline[gridDim.x + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    a.timeline[2 * gridDim.x + blockIdx.x] = (uint64_t)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID
   }
 }
 
@@ -1213,7 +1264,7 @@ static hipError_t launch_scan_v(const ScanArgs& a, int grid, hipStream_t st) {
 
 template <typename T, int D, bool DENSE, bool NT = false, bool L2 = false>
 static hipError_t launch_scan16(const ScanArgs& a, int grid, hipStream_t st) {
-  const size_t lds = 3 * (size_t)kTileRows * D * 2 + (L2 ? 3 * 256 : 0);
+  const size_t lds = 3 * (size_t)kTileRows * D * 2 + 3 * 256 + 16;  // ring + L2 norm slots + ticket words
   hipError_t e = hipFuncSetAttribute((const void*)flat_scan16_kernel<T, D, DENSE, NT, L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((flat_scan16_kernel<T, D, DENSE, NT, L2>), dim3(grid), dim3(256), lds, st, a);
