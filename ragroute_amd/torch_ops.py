@@ -1,0 +1,102 @@
+"""torch.library custom ops over the C ABI (`torch.ops.ragroute.*`), the operator surface proposed in SURVEY §8b:
+
+    ragroute::flat_topk(xb, xq, k, id_offset=0, l2=False) -> (D f32[nq,k], I i64[nq,k])     index.search, data_source.py:158,186,203
+    ragroute::l2_normalize_(x) -> x                                                         faiss.normalize_L2, data_source.py:199
+    ragroute::merge_topk(D, I, k, descending=True) -> (D, I)                                rerank.py:3-9, 28-34
+    ragroute::rows_to_half(x, dim, bf16=False, normalize=False) -> Tensor                   ingest / query conversion
+
+All take and return CUDA tensors, enqueue on the current stream and never synchronise.  The faiss-shaped classes in
+flat_index.py are thin conveniences over the same entry points (they additionally cache the workspace)."""
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+_WS = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _workspace(device, k):
+    key = (device.index, k)
+    ws = _WS.get(key)
+    if ws is None:
+        nbytes = lib().rr_flat_search_workspace_bytes(k)
+        if nbytes == 0:
+            raise ValueError(f"k must be in [1, {_lib.RR_MAX_K}]")
+        _WS.clear()
+        ws = _WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return ws
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float16:
+        return _lib.RR_DTYPE_F16
+    if t.dtype == torch.bfloat16:
+        return _lib.RR_DTYPE_BF16
+    raise ValueError("corpus / queries must be float16 or bfloat16")
+
+
+@torch.library.custom_op("ragroute::flat_topk", mutates_args=())
+def flat_topk(xb: torch.Tensor, xq: torch.Tensor, k: int, id_offset: int = 0, l2: bool = False) -> tuple[torch.Tensor, torch.Tensor]:
+    if not (xb.is_cuda and xq.is_cuda and xb.dim() == 2 and xq.dim() == 2 and xb.shape[1] == xq.shape[1] and xb.dtype == xq.dtype):
+        raise ValueError("flat_topk: xb [n,dim] and xq [nq,dim] must be CUDA tensors of the same half dtype and padded width")
+    xb, xq = xb.contiguous(), xq.contiguous()
+    n, dim = xb.shape
+    nq = xq.shape[0]
+    D = torch.empty((nq, k), dtype=torch.float32, device=xb.device)
+    I = torch.empty((nq, k), dtype=torch.int64, device=xb.device)
+    ws = _workspace(xb.device, k)
+    with torch.cuda.device(xb.device):
+        if l2:
+            hn = torch.empty(max(1, n), dtype=torch.float32, device=xb.device)
+            check(lib().rr_half_sqnorms(xb.data_ptr(), _dtype_code(xb), n, dim, hn.data_ptr(), _stream()), "rr_half_sqnorms")
+            check(lib().rr_flat_search_l2(xb.data_ptr(), hn.data_ptr(), _dtype_code(xb), n, dim, xq.data_ptr(), nq, k, D.data_ptr(),
+                                          I.data_ptr(), id_offset, ws.data_ptr(), ws.numel(), None, 0, _stream()), "rr_flat_search_l2")
+        else:
+            check(lib().rr_flat_search(xb.data_ptr(), _dtype_code(xb), n, dim, xq.data_ptr(), nq, k, D.data_ptr(), I.data_ptr(),
+                                       id_offset, ws.data_ptr(), ws.numel(), None, 0, _stream()), "rr_flat_search")
+    return D, I
+
+
+@flat_topk.register_fake
+def _(xb, xq, k, id_offset=0, l2=False):
+    return xq.new_empty((xq.shape[0], k), dtype=torch.float32), xq.new_empty((xq.shape[0], k), dtype=torch.int64)
+
+
+@torch.library.custom_op("ragroute::l2_normalize_", mutates_args=("x",))
+def l2_normalize_(x: torch.Tensor) -> None:
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()):
+        raise ValueError("l2_normalize_: contiguous float32 CUDA matrix expected")
+    with torch.cuda.device(x.device):
+        check(lib().rr_l2_normalize_f32(x.data_ptr(), x.shape[0], x.shape[1], _stream()), "rr_l2_normalize_f32")
+
+
+@torch.library.custom_op("ragroute::merge_topk", mutates_args=())
+def merge_topk(D: torch.Tensor, I: torch.Tensor, k: int, descending: bool = True) -> tuple[torch.Tensor, torch.Tensor]:
+    from .rerank import merge_topk as _merge
+    return _merge(D, I, k, descending)
+
+
+@merge_topk.register_fake
+def _(D, I, k, descending=True):
+    return D.new_empty((D.shape[0], k), dtype=torch.float32), I.new_empty((I.shape[0], k), dtype=torch.int64)
+
+
+@torch.library.custom_op("ragroute::rows_to_half", mutates_args=())
+def rows_to_half(x: torch.Tensor, dim: int, bf16: bool = False, normalize: bool = False) -> torch.Tensor:
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
+        raise ValueError("rows_to_half: float32 CUDA matrix expected")
+    x = x.contiguous()
+    out = torch.empty((x.shape[0], dim), dtype=torch.bfloat16 if bf16 else torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().rr_rows_to_half(x.data_ptr(), x.shape[0], x.shape[1], x.shape[1], out.data_ptr(),
+                                    _lib.RR_DTYPE_BF16 if bf16 else _lib.RR_DTYPE_F16, dim, int(normalize), _stream()), "rr_rows_to_half")
+    return out
+
+
+@rows_to_half.register_fake
+def _(x, dim, bf16=False, normalize=False):
+    return x.new_empty((x.shape[0], dim), dtype=torch.bfloat16 if bf16 else torch.float16)

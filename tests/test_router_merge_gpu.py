@@ -277,3 +277,26 @@ def test_pipeline_mixed_encoders_feb4rag_shapes(gpu):
         cand_I.append(Is + (s << SHARD_SHIFT))
     Dr, Ir = O.merge_topk(np.concatenate(cand_D, 1), np.concatenate(cand_I, 1), 10, True)
     assert np.array_equal(D.cpu().numpy(), Dr) and np.array_equal(I.cpu().numpy(), Ir)
+
+
+def test_torch_custom_ops(gpu):
+    """torch.ops.ragroute.* reach the same kernels: convert -> flat_topk -> merge_topk against the oracle."""
+    from oracle import oracle as O
+    import ragroute_amd.torch_ops  # noqa: F401  (registers the ops)
+    rng = np.random.default_rng(9)
+    xb, xq = int_data(rng, 25_000, 300), int_data(rng, 12, 300)
+    dim = 384
+    xbh = torch.ops.ragroute.rows_to_half(torch.from_numpy(xb).to(gpu), dim)
+    xqh = torch.ops.ragroute.rows_to_half(torch.from_numpy(xq).to(gpu), dim)
+    D, I = torch.ops.ragroute.flat_topk(xbh, xqh, 10)
+    Dr, Ir = O.flat_search_ip(xb, xq, 10)
+    assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr)
+    D2, I2 = torch.ops.ragroute.flat_topk(xbh, xqh, 10, 0, True)
+    Dl, Il = O.flat_search_l2(xb, xq, 10)
+    assert np.array_equal(I2.cpu().numpy(), Il) and np.array_equal(D2.cpu().numpy(), Dl)
+    Dm, Im = torch.ops.ragroute.merge_topk(torch.cat([D, D], 1), torch.cat([I, I + (1 << 40)], 1), 10)
+    assert torch.equal(Im[:, 0], I[:, 0]) and torch.equal(Dm[:, 0], D[:, 0])
+    x = torch.from_numpy(rng.standard_normal((50, 77)).astype(np.float32)).to(gpu)
+    want = x / x.norm(dim=1, keepdim=True)
+    torch.ops.ragroute.l2_normalize_(x)
+    assert torch.allclose(x, want, atol=1e-6)
