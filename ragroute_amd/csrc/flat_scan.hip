@@ -536,34 +536,6 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   const int col = lane & 15, g = lane >> 4;
   if (a.timeline && threadIdx.x == 0) a.timeline[blockIdx.x] = __builtin_amdgcn_s_memrealtime();  // diagnostics only
 
-  // ---- resident queries: B fragment (qb, s2): query wave*64 + qb*16 + col, k = 32 s2 + 8 g .. +7 -------------
-  frag q[4][KS2];
-  {
-    const T* xq = (const T*)a.xq;
-#pragma unroll
-    for (int qb = 0; qb < 4; ++qb) {
-      const uint32_t qi = wave * 64 + qb * 16 + col;
-      const T* p = xq + (size_t)(qi < a.nq ? qi : a.nq - 1) * D + 8 * g;
-#pragma unroll
-      for (int s2 = 0; s2 < KS2; ++s2) {
-        if (qb * KS2 + s2 < NAQ) agpr_load_frag(q[qb][s2], p + 32 * s2);
-        else q[qb][s2] = *(const frag*)(p + 32 * s2);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NAQ; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+a"(q[i / KS2][i % KS2]));
-  }
-
-  LaneState4 st;
-  const uint32_t nbuf = gridDim.x * 4;
-#pragma unroll
-  for (int qb = 0; qb < 4; ++qb) {
-    const uint32_t qi = wave * 64 + qb * 16 + col;
-    st.thr[qb] = DENSE ? 0.f : a.thr[qi];
-    st.cnt[qb] = 0;
-    st.off[qb] = (qi * nbuf + blockIdx.x * 4 + g) * (uint32_t)a.cap;
-  }
-
   // ---- LDS image (identical to flat_scan_kernel's).  A fragment (rb, s2): row rb*16 + col, chunk 4*(s2&1) + g of
   // k group s2>>1 -------------------------------------------------------------------------------------------------
   uint32_t roff[2][2];
@@ -646,6 +618,36 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
 #pragma unroll
     for (int kg = 0; kg < KG; ++kg) issue_piece(g1, 1, kg);
   }
+
+  // (the first two tiles are already in flight: their HBM latency overlaps the query loads below)
+  // ---- resident queries: B fragment (qb, s2): query wave*64 + qb*16 + col, k = 32 s2 + 8 g .. +7 -------------
+  frag q[4][KS2];
+  {
+    const T* xq = (const T*)a.xq;
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      const uint32_t qi = wave * 64 + qb * 16 + col;
+      const T* p = xq + (size_t)(qi < a.nq ? qi : a.nq - 1) * D + 8 * g;
+#pragma unroll
+      for (int s2 = 0; s2 < KS2; ++s2) {
+        if (qb * KS2 + s2 < NAQ) agpr_load_frag(q[qb][s2], p + 32 * s2);
+        else q[qb][s2] = *(const frag*)(p + 32 * s2);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NAQ; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+a"(q[i / KS2][i % KS2]));
+  }
+
+  LaneState4 st;
+  const uint32_t nbuf = gridDim.x * 4;
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) {
+    const uint32_t qi = wave * 64 + qb * 16 + col;
+    st.thr[qb] = DENSE ? 0.f : a.thr[qi];
+    st.cnt[qb] = 0;
+    st.off[qb] = (qi * nbuf + blockIdx.x * 4 + g) * (uint32_t)a.cap;
+  }
+
   int slot = 0, par = 0, sub = kTicketBatch;
   uint32_t base = 0, dbg_iter = 0;
   while (j < n_tiles) {
@@ -663,7 +665,10 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
       if (lane == 0) ticket_lds[par] = 2 * stride + ticket;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // a raw s_barrier does not wait for the LDS store
     }
-    if (a.timeline && threadIdx.x == 0) a.timeline[3 * gridDim.x + blockIdx.x * 64 + (dbg_iter++ & 63)] = j;  // diagnostics only
+    if (a.timeline && threadIdx.x == 0) {  // diagnostics only: tile sequence, and the time the first tile became ready
+      if (dbg_iter == 0) a.timeline[3 * gridDim.x + 64 * gridDim.x + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+      a.timeline[3 * gridDim.x + blockIdx.x * 64 + (dbg_iter++ & 63)] = j;
+    }
     __builtin_amdgcn_s_barrier();
     int nslot = slot + 2;
     if (nslot >= 3) nslot -= 3;

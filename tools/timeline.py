@@ -21,11 +21,14 @@ torch.cuda.synchronize()
 ws = idx._ws[k]
 grid = 256
 off = 1024 + 1024 + 1024 + 256 * 1024 * 8 + 256 * grid * 4 * 4 + grid * 8 * 64 * 8
-t = ws[off: off + 3 * grid * 8].view(torch.int64).reshape(3, grid).cpu().double()
+raw = ws[off: off + (3 * grid + 65 * grid) * 8].view(torch.int64).cpu().double()
+t = raw[: 3 * grid].reshape(3, grid)
+first_ready = raw[3 * grid + 64 * grid:] / 100.0
 start, end, xcc = t[0] / 100.0, t[1] / 100.0, t[2]   # us
 t0 = start.min()
 print(f"launch span {(end.max() - t0).item():.1f} us; starts spread {(start.max() - t0).item():.1f} us")
 dur = end - start
+print(f"first tile ready after start: median {(first_ready - start).median().item():.2f} us, max {(first_ready - start).max().item():.2f} us")
 print(f"workgroup durations: min {dur.min().item():.1f} median {dur.median().item():.1f} max {dur.max().item():.1f} us")
 print(f"ends: first {(end.min() - t0).item():.1f} median {(end.median() - t0).item():.1f} last {(end.max() - t0).item():.1f} us  -> tail after median {(end.max() - end.median()).item():.1f} us")
 for x in range(8):
