@@ -204,10 +204,43 @@ def cpu_baseline(idx, xq, n, d, k):
     parity = {"recall_at_k": round(recall, 6), "rank_order_identical_queries": int(sum(np.array_equal(Ig[i], Ir[i]) for i in range(nchk))),
               "queries_checked": nchk, "max_abs_score_diff": float(np.abs(Dg - Dr).max()),
               "sample": f"GPU top-{k} of the first {sample} rows vs oracle.flat_search_ip (f64 dot products of the same fp16-rounded values)"}
+    extra = cpu_extra_rows(O, xb, q, k, sample, n)
     return {"value": round(qps_sample * sample / n, 3), "unit": "queries/sec", "cores": O.num_threads(), "kind": "port",
             "sample": f"{calls} single-query f32 searches (nq=1 per call, as the reference issues them) over the first {sample} rows "
                       f"in {dt:.2f} s = {qps_sample:.2f} q/s on the sample, scaled x{sample / n:.3g} to {n} rows",
-            "parity_vs_cpu": parity}
+            "parity_vs_cpu": parity, "other_rows": extra}
+
+
+def cpu_extra_rows(O, xb, q, k, sample, n):
+    """BASELINE.md rows C2-C4 on the same host cores (context only): batched sgemm + top-k, router forward, merge."""
+    t0 = time.perf_counter()
+    S = q @ xb.T                                             # C2: nq = 256 blocked sgemm (numpy BLAS) + per-query top-k
+    idx = np.argpartition(-S, k, axis=1)[:, :k]
+    np.take_along_axis(S, idx, axis=1).sort(axis=1)
+    c2 = len(q) / (time.perf_counter() - t0) * sample / n
+    rng = np.random.default_rng(0)                           # C3: reference-shaped router step per query (router.py:241-283)
+    C, d = 4, q.shape[1]
+    sd = {"fc1.weight": rng.standard_normal((256, 2 * d + C)).astype(np.float32) * 0.02, "fc1.bias": np.zeros(256, np.float32),
+          "ln1.weight": np.ones(256, np.float32), "ln1.bias": np.zeros(256, np.float32),
+          "fc2.weight": rng.standard_normal((128, 256)).astype(np.float32) * 0.05, "fc2.bias": np.zeros(128, np.float32),
+          "ln2.weight": np.ones(128, np.float32), "ln2.bias": np.zeros(128, np.float32),
+          "fc3.weight": rng.standard_normal((1, 128)).astype(np.float32) * 0.1, "fc3.bias": np.zeros(1, np.float32)}
+    srcs = [str(i) for i in range(C)]
+    cen = {s: rng.standard_normal(d).astype(np.float32) for s in srcs}
+    mean, scale = np.zeros(2 * d + C), np.ones(2 * d + C)
+    t0 = time.perf_counter()
+    for i in range(64):
+        lg = O.router_logits("medrag", srcs, {s: "m" for s in srcs}, {s: j for j, s in enumerate(srcs)}, d, {"m": q[i]}, cen, sd, mean, scale)
+        O.router_select("medrag", srcs, lg)
+    c3 = 64 / (time.perf_counter() - t0)
+    cand = rng.standard_normal(4 * k).tolist()               # C4: np.argsort merge of S*k candidates per query (rerank.py:3-9)
+    docs = list(range(4 * k))
+    t0 = time.perf_counter()
+    for _ in range(2000):
+        O.rerank_medrag(docs, cand, k)
+    c4 = 2000 / (time.perf_counter() - t0)
+    return {"C2_batched_sgemm_topk_queries_per_s_scaled": round(c2, 2), "C3_router_numpy_queries_per_s": round(c3, 1),
+            "C4_merge_numpy_queries_per_s": round(c4, 1)}
 
 
 if __name__ == "__main__":
