@@ -54,7 +54,22 @@ __global__ __launch_bounds__(256) void rows_to_half_kernel(const float* x, int64
       if (nr > 0.f) inv = 1.0f / sqrtf(nr);
     }
     T* o = out + row * d_out;
-    for (int64_t i = lane; i < d_out; i += 64) o[i] = i < d ? (T)(xr[i] * inv) : (T)0.f;
+    if ((d & 3) == 0 && (d_out & 3) == 0 && ((((uintptr_t)xr) | ((uintptr_t)o << 1)) & 15) == 0) {
+      // 16-byte loads, 8-byte stores (Guideline 13: hipcc does not vectorise these by itself)
+      typedef T vec4 __attribute__((ext_vector_type(4)));
+      const float4* x4 = (const float4*)xr;
+      vec4* o4 = (vec4*)o;
+      for (int64_t i = lane; i < d_out / 4; i += 64) {
+        vec4 h = {(T)0.f, (T)0.f, (T)0.f, (T)0.f};
+        if (i < d / 4) {
+          const float4 v = x4[i];
+          h = vec4{(T)(v.x * inv), (T)(v.y * inv), (T)(v.z * inv), (T)(v.w * inv)};
+        }
+        o4[i] = h;
+      }
+    } else {
+      for (int64_t i = lane; i < d_out; i += 64) o[i] = i < d ? (T)(xr[i] * inv) : (T)0.f;
+    }
   }
 }
 
