@@ -9,11 +9,12 @@
 //    32-row tiles through a 3-slot ring (2 tiles in flight per CU); every 1 KiB DMA piece is
 //    8 rows x 128 contiguous bytes (whole cache lines), XOR-swizzled on the SOURCE side so the
 //    later ds_read_b128 of MFMA A-fragments is bank-conflict-free.
-//  * Per tile: KS x { ds_read_b128 corpus fragment ; 2 x v_mfma_f32_32x32x16 } with the corpus as
-//    A and the queries as B, so every lane ends up owning ONE query (column) and 16 corpus rows:
-//    the top-k filter is a per-lane compare against that query's threshold, no cross-lane work.
+//  * Per tile: 48 x { ds_read_b128 corpus fragment ; 4 x v_mfma_f32_16x16x32 } (default shape; 2 x 32x32x16 in the
+//    older form) with the corpus as A and the queries as B, so every lane ends up owning ONE query (column) and a
+//    few corpus rows per result block: the top-k filter is a per-lane compare against that query's threshold, no
+//    cross-lane work.  No inter-workgroup reuse exists (every byte is read once), so no XCD-aware block remap.
 //  * Scores strictly above the threshold are appended (as 64-bit order keys) to a private
-//    per-(workgroup, query, lane-half) buffer; if a buffer fills, the wave compacts it exactly
+//    per-(workgroup, query, lane-quarter) buffer; if a buffer fills, the wave compacts it exactly
 //    to its k best and raises that lane's threshold.  Nothing is ever dropped that could be in
 //    the final top-k (see DESIGN.md "exactness").
 //  * DENSE=true writes every score instead (bootstrap sample and tiny corpora).
