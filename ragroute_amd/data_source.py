@@ -18,8 +18,10 @@ from .flat_index import FlatIndex, normalize_L2
 logger = logging.getLogger("client")
 
 
-def read_faiss_flat_index(path):
+def read_faiss_flat_index(path, mmap=True):
     """Minimal reader for a FAISS IndexFlat file ("IxFI"/"IxF2"): returns (float32 [ntotal,d], metric).
+    With mmap=True (default) the payload is memory-mapped, so a 70 GB index (MedRAG pubmed: 23.9 M x 768 f32) is streamed
+    into HBM chunk by chunk by FlatIndex.add instead of being loaded into host RAM first.
     Layout per FAISS's index_write.cpp (1.7.x): fourcc, d:i32, ntotal:i64, 2 x i64 dummy, is_trained:u8,
     metric_type:i32 [, metric_arg:f32 if metric_type > 1], then size:u64 (in floats) + payload.
     Format knowledge is external to the reference tree and unverified against a real faiss file here."""
@@ -37,7 +39,11 @@ def read_faiss_flat_index(path):
         nfloat = int(np.frombuffer(f.read(8), np.uint64)[0])
         if nfloat != ntotal * d:
             raise ValueError(f"{path}: payload of {nfloat} floats does not match ntotal*d = {ntotal * d}")
-        xb = np.fromfile(f, dtype=np.float32, count=nfloat).reshape(ntotal, d)
+        offset = f.tell()
+        if mmap and ntotal > 0:
+            xb = np.memmap(path, dtype=np.float32, mode="r", offset=offset, shape=(ntotal, d))
+        else:
+            xb = np.fromfile(f, dtype=np.float32, count=nfloat).reshape(ntotal, d)
     return xb, ("ip" if metric_type == 0 else "l2")
 
 
@@ -95,7 +101,8 @@ class DataSource:
     # -- loading (data_source.py:69-80) -------------------------------------------------------------
     def load_faiss_index(self):
         logger.info(f"Loading FAISS index for {self.name}")
-        xb, _ = read_faiss_flat_index(self.index_path)
+        xb, file_metric = read_faiss_flat_index(self.index_path)
+        self.index_metric = file_metric  # the index FILE decides the metric in the reference (faiss.read_index, data_source.py:71)
         if self.dataset == "medrag":
             metadatas = [json.loads(line) for line in open(self.doc_ids_path).read().strip().split("\n")]
         elif self.dataset == "feb4rag":
@@ -111,11 +118,15 @@ class DataSource:
         self.set_index(xb, metadatas)
 
     def set_index(self, xb, metadatas, titles=None, texts=None):
-        """Install a corpus directly: xb float32 [n,d] (numpy) or an existing FlatIndex."""
+        """Install a corpus directly: xb float32 [n,d] (numpy / memmap) or an existing FlatIndex."""
         if isinstance(xb, FlatIndex):
             index = xb
         else:
-            index = FlatIndex(xb.shape[1], metric="ip", dtype=self.dtype)
+            metric = getattr(self, "index_metric", "ip")
+            if metric == "l2" and xb.shape[1] > 768:
+                raise NotImplementedError("L2 flat indexes wider than 768 are not supported yet")
+            index = FlatIndex(xb.shape[1], metric=metric, dtype=self.dtype)
+            index.reserve(xb.shape[0])
             index.add(xb)
         self.faiss_indexes = index, metadatas
         if titles is not None:

@@ -89,7 +89,7 @@ class FlatIndex:
             for s in range(0, n, chunk_rows):
                 e = min(n, s + chunk_rows)
                 part = x[s:e]
-                if isinstance(part, np.ndarray):
+                if isinstance(part, np.ndarray):  # also np.memmap: only this chunk is paged in
                     part = torch.from_numpy(np.ascontiguousarray(part, dtype=np.float32))
                 part = part.to(self.device, dtype=torch.float32).contiguous()
                 out = self._xb[self.ntotal + s : self.ntotal + e]

@@ -59,7 +59,11 @@ def test_flat_index_file_round_trip(tmp_path):
     p = str(tmp_path / "x.index")
     write_faiss_flat_index(p, xb, "ip")
     got, metric = read_faiss_flat_index(p)
-    assert metric == "ip" and np.array_equal(got, xb)
+    assert metric == "ip" and np.array_equal(got, xb) and isinstance(got, np.memmap)
+    got2, _ = read_faiss_flat_index(p, mmap=False)
+    assert np.array_equal(got2, xb) and not isinstance(got2, np.memmap)
+    write_faiss_flat_index(p, xb, "l2")
+    assert read_faiss_flat_index(p)[1] == "l2"
     open(p, "r+b").write(b"IwFl")
     with pytest.raises(ValueError):
         read_faiss_flat_index(p)
