@@ -90,7 +90,8 @@ class FlatIndex:
                 e = min(n, s + chunk_rows)
                 part = x[s:e]
                 if isinstance(part, np.ndarray):  # also np.memmap: only this chunk is paged in
-                    part = torch.from_numpy(np.ascontiguousarray(part, dtype=np.float32))
+                    part = np.ascontiguousarray(part, dtype=np.float32)
+                    part = torch.from_numpy(part if part.flags.writeable else part.copy())
                 part = part.to(self.device, dtype=torch.float32).contiguous()
                 out = self._xb[self.ntotal + s : self.ntotal + e]
                 check(lib().rr_rows_to_half(part.data_ptr(), e - s, self.d, self.d, out.data_ptr(), _RR_DTYPE[self.dtype],
