@@ -152,3 +152,28 @@ def test_load_router_reads_the_reference_file_formats(tmp_path):
         bad = dict(wcase["sd"])
         del bad["ln2.bias"]
         w.router.load_state_dict(bad)
+
+
+def test_compat_shim_resolves_hot_path_modules_to_ragroute_amd():
+    """compat/ragroute: router/data_source/rerank come from ragroute_amd; other modules fall through to the reference checkout
+    (only checked where one is mounted: it never travels to the GPU box)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = "/root/reference"
+    code = ("import ragroute.rerank as r, ragroute.router as ro, ragroute.data_source as ds\n"
+            "assert r.rerank_medrag.__module__ == 'ragroute_amd.rerank'\n"
+            "assert ro.Router.__module__ == 'ragroute_amd.router' and ds.DataSource.__module__ == 'ragroute_amd.data_source'\n"
+            "import os\n"
+            "if os.environ.get('RAGROUTE_REFERENCE_DIR'):\n"
+            "    import ragroute.config as c, ragroute.queue_manager as q\n"
+            "    assert c.__file__.startswith(os.environ['RAGROUTE_REFERENCE_DIR']) and c.K['medrag'] == 32\n"
+            "    assert q.QueryQueue.__module__ == 'ragroute.queue_manager'\n"
+            "print('shim ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "compat") + os.pathsep + root)
+    if os.path.isdir(os.path.join(ref, "ragroute")):
+        env["RAGROUTE_REFERENCE_DIR"] = ref
+    else:
+        env.pop("RAGROUTE_REFERENCE_DIR", None)
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and "shim ok" in res.stdout, res.stderr[-1500:]
