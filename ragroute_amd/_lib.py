@@ -42,7 +42,7 @@ def lib():
             raise RagrouteHipError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built. "
                 "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(os.environ.get("RR_LIB_OVERRIDE", LIB_PATH))  # RR_LIB_OVERRIDE: A/B builds during development
         vp, i64, i32, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
         L.rr_version.restype = i32
         L.rr_last_error.restype = ctypes.c_char_p
