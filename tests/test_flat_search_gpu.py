@@ -257,3 +257,13 @@ def test_dynamic_tile_tickets_option(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "dynamic ok" in res.stdout, res.stderr[-2000:]
+
+
+def test_l2_metric_bf16_and_single_query(gpu):
+    """L2 on bf16 storage, and the small-batch path (1 query: three of the four waves only feed the DMA ring)."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(21)
+    xb, xq = int_data(rng, 70_000, 640), int_data(rng, 1, 640)
+    D, I = _index(gpu, xb, 640, metric="l2", dtype="bf16").search(xq, 10)
+    Dref, Iref = O.flat_search_l2(xb, xq, 10)
+    assert np.array_equal(I, Iref) and np.array_equal(D, Dref)
