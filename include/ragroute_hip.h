@@ -92,6 +92,26 @@ int rr_flat_search_l2(const void* d_xb, const float* d_half_sqnorm, int dtype, i
 /* |x|^2 / 2 (f32) of every row of a stored corpus, computed from the stored (rounded) values. */
 int rr_half_sqnorms(const void* d_xb, int dtype, int64_t n_rows, int dim, float* d_out, void* stream);
 
+/* ---- Optional: the same exact inner-product top-k through an int8 screening copy --------------------------------------
+ * Same call site as rr_flat_search (`index.search`, ragroute/data_source.py:158,186,203) and the same results; the
+ * reference has no counterpart (faiss.IndexFlatIP reads every f32 row).  The corpus keeps its f16/bf16 rows and one int8
+ * copy beside them (+50 % HBM); a search streams only the int8 copy (half the bytes, twice the MFMA rate) to rank rows by
+ * the integer dot product, keeps the list_len best per query, re-scores those from the f16/bf16 rows in f32 and checks a
+ * rigorous quantisation-error bound: d_exact[q] = 1 means the returned k rows are proven to be the exact top-k of the
+ * f16/bf16 corpus; 0 means the proof failed for that query (list_len too short for this data) and the caller must repeat the
+ * batch with rr_flat_search.  Inner product / cosine only; dim <= 1536.
+ *   rr_screen_dim(dim)   bytes per int8 row for rows of dim f16/bf16 elements (next multiple of 256), <0 if unsupported
+ *   rr_screen_build      d_x8 device int8 [n_rows][rr_screen_dim(dim)] and d_stats device f32[8] (corpus scale and error
+ *                        maxima) from the stored rows; rebuild after the corpus changes
+ *   rr_flat_search_screened  arguments as rr_flat_search, plus d_x8 / d_stats, list_len in [k, 1024] and d_exact u8 [nq]. */
+int rr_screen_dim(int dim);
+int rr_screen_build(const void* d_xb, int dtype, int64_t n_rows, int dim, void* d_x8, float* d_stats, void* stream);
+size_t rr_flat_search_screened_workspace_bytes(int k, int list_len, int nq, int dim);
+int rr_flat_search_screened(const void* d_xb, int dtype, const void* d_x8, const float* d_stats, int64_t n_rows, int dim,
+                            const void* d_xq, int nq, int k, int list_len, float* d_D, int64_t* d_I, int64_t id_offset,
+                            uint8_t* d_exact, void* d_ws, size_t ws_bytes, const uint8_t* d_route_mask, int64_t mask_stride,
+                            void* stream);
+
 /* Measurement aid (bench.py): between rr_profile_begin and rr_profile_end every launch of the scan
  * kernel made by rr_flat_search on the calling thread is bracketed by HIP events on the launch stream.
  * rr_profile_end waits for them and returns the summed kernel time, the number of launches and the

@@ -4,12 +4,12 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libragroute_hip.so")
-SOURCES = ["capi.hip", "flat_scan.hip", "select.hip", "prep.hip", "router.hip"]
+SOURCES = ["capi.hip", "flat_scan.hip", "select.hip", "prep.hip", "router.hip", "screen.hip"]
 
 
 def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("rr_common.h", "rr_kernels.h")] + [
+    deps = srcs + [os.path.join(CSRC, h) for h in ("rr_common.h", "rr_kernels.h", "rr_sort.h")] + [
         os.path.join(os.path.dirname(CSRC), "..", "include", "ragroute_hip.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH

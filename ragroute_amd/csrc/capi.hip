@@ -156,7 +156,7 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
   if (k < 1 || k > kMaxK) return fail(RR_ERR_INVALID, "rr_flat_search: k must be in [1, 1024]%s");
   if (nq < 0 || n_rows < 0) return fail(RR_ERR_INVALID, "rr_flat_search: negative size%s");
   if (n_rows > 0xFFFFFFE0ll) return fail(RR_ERR_UNSUPPORTED, "rr_flat_search: more than 2^32-32 rows per shard%s");
-  if (dtype != RR_DTYPE_F16 && dtype != RR_DTYPE_BF16) return fail(RR_ERR_INVALID, "rr_flat_search: bad dtype%s");
+  if (dtype != RR_DTYPE_F16 && dtype != RR_DTYPE_BF16 && dtype != kDtypeI8) return fail(RR_ERR_INVALID, "rr_flat_search: bad dtype%s");
   if (scan_padded_dim(dim) != dim)
     return fail(RR_ERR_UNSUPPORTED, "rr_flat_search: dim must equal rr_padded_dim(d)%s");
   if (nq == 0) return RR_OK;
@@ -183,7 +183,7 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
     memset(&s, 0, sizeof(s));
     s.thr = w.thr; s.list = w.list; s.list_cnt = w.list_cnt; s.tile_counters = w.tile_counters; s.cand = w.cand; s.cand_cnt = w.cand_cnt;
     s.dense = w.dense; s.dense_ld = kSampleRows; s.n_rows = (uint32_t)n_rows; s.nq = (uint32_t)nqb;
-    s.nbuf = (uint32_t)grid * (uint32_t)scan_bufs_per_wg(dim); s.list_ld = kMaxK; s.cap = cap; s.k = k;
+    s.nbuf = (uint32_t)grid * (uint32_t)(dtype == kDtypeI8 ? 4 : scan_bufs_per_wg(dim)); s.list_ld = kMaxK; s.cap = cap; s.k = k;
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     a.xb = xb; a.xq = xq_b; a.thr = w.thr; a.cand = w.cand; a.cand_cnt = w.cand_cnt; a.scratch = w.scratch;
@@ -230,6 +230,7 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
 int rr_flat_search(const void* xb, int dtype, int64_t n_rows, int dim, const void* xq, int nq, int k, float* D,
                    int64_t* I, int64_t id_offset, void* ws, size_t ws_bytes, const uint8_t* route_mask,
                    int64_t mask_stride, void* stream) {
+  if (dtype != RR_DTYPE_F16 && dtype != RR_DTYPE_BF16) return fail(RR_ERR_INVALID, "rr_flat_search: bad dtype%s");
   return flat_search_impl(xb, dtype, n_rows, dim, xq, nq, k, D, I, id_offset, ws, ws_bytes, route_mask, mask_stride, nullptr, stream);
 }
 
@@ -242,6 +243,71 @@ int rr_flat_search_l2(const void* xb, const float* half_sqnorm, int dtype, int64
   static const float kEmpty = 0.f;
   return flat_search_impl(xb, dtype, n_rows, dim, xq, nq, k, D, I, id_offset, ws, ws_bytes, route_mask, mask_stride,
                           half_sqnorm ? half_sqnorm : &kEmpty, stream);
+}
+
+// ---- int8 screening copy ---------------------------------------------------------------------------------
+struct ScreenWs { int8_t* q8; float* qinfo; float* PL; int64_t* IL; char* inner; size_t inner_bytes, total; };
+static ScreenWs carve_screen(char* base, int list_len, int nq, int dim8, int grid) {
+  ScreenWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return base ? base + o : (char*)nullptr; };
+  w.q8 = (int8_t*)take((size_t)nq * dim8);
+  w.qinfo = (float*)take((size_t)nq * 2 * sizeof(float));
+  w.PL = (float*)take((size_t)nq * list_len * sizeof(float));
+  w.IL = (int64_t*)take((size_t)nq * list_len * sizeof(int64_t));
+  w.inner_bytes = carve(nullptr, list_len, grid).total;
+  w.inner = take(w.inner_bytes);
+  w.total = off;
+  return w;
+}
+
+int rr_screen_dim(int dim) {
+  if (dim < 8 || dim % 8 != 0) return RR_ERR_INVALID;
+  const int d8 = (dim + 255) / 256 * 256;
+  return d8 <= 2 * rr::kMaxResidentDim ? d8 : RR_ERR_UNSUPPORTED;
+}
+
+int rr_screen_build(const void* xb, int dtype, int64_t n_rows, int dim, void* x8, float* stats, void* stream) {
+  const int dim8 = rr_screen_dim(dim);
+  if (dim8 < 0) return fail(dim8, "rr_screen_build: the int8 screening copy needs dim <= 1536, a multiple of 8%s");
+  if (n_rows < 0 || !stats || ((!xb || !x8) && n_rows > 0)) return fail(RR_ERR_INVALID, "rr_screen_build: bad arguments%s");
+  if (dtype != RR_DTYPE_F16 && dtype != RR_DTYPE_BF16) return fail(RR_ERR_INVALID, "rr_screen_build: bad dtype%s");
+  hipError_t e = rr::launch_screen_build(xb, dtype, n_rows, dim, (int8_t*)x8, dim8, (uint32_t*)stats, (hipStream_t)stream);
+  return e == hipSuccess ? RR_OK : hip_fail(e, "rr_screen_build");
+}
+
+size_t rr_flat_search_screened_workspace_bytes(int k, int list_len, int nq, int dim) {
+  const int dim8 = rr_screen_dim(dim);
+  if (k < 1 || list_len < k || list_len > rr::kMaxK || nq < 0 || dim8 < 0) return 0;
+  int grid = device_cus();
+  if (grid <= 0) return 0;
+  return carve_screen(nullptr, list_len, nq, dim8, grid).total;
+}
+
+int rr_flat_search_screened(const void* xb, int dtype, const void* x8, const float* stats, int64_t n_rows, int dim, const void* xq,
+                            int nq, int k, int list_len, float* D, int64_t* I, int64_t id_offset, uint8_t* exact, void* ws,
+                            size_t ws_bytes, const uint8_t* route_mask, int64_t mask_stride, void* stream) {
+  using namespace rr;
+  hipStream_t st = (hipStream_t)stream;
+  const int dim8 = rr_screen_dim(dim);
+  if (dim8 < 0) return fail(RR_ERR_UNSUPPORTED, "rr_flat_search_screened: dim must be a multiple of 8, <= 1536%s");
+  if (k < 1 || list_len < k || list_len > kMaxK) return fail(RR_ERR_INVALID, "rr_flat_search_screened: need 1 <= k <= list_len <= 1024%s");
+  if (dtype != RR_DTYPE_F16 && dtype != RR_DTYPE_BF16) return fail(RR_ERR_INVALID, "rr_flat_search_screened: bad dtype%s");
+  if (nq < 0 || n_rows < 0) return fail(RR_ERR_INVALID, "rr_flat_search_screened: negative size%s");
+  if (nq == 0) return RR_OK;
+  if (!xq || !D || !I || !exact || !ws || !stats || ((!xb || !x8) && n_rows > 0))
+    return fail(RR_ERR_INVALID, "rr_flat_search_screened: null pointer%s");
+  const int grid = device_cus();
+  if (grid <= 0) return fail(RR_ERR_HIP, "rr_flat_search_screened: no HIP device%s");
+  ScreenWs w = carve_screen((char*)ws, list_len, nq, dim8, grid);
+  if (ws_bytes < w.total) return fail(RR_ERR_WORKSPACE, "rr_flat_search_screened: workspace smaller than rr_flat_search_screened_workspace_bytes%s");
+  hipError_t e = launch_screen_queries(xq, dtype, nq, dim, w.q8, dim8, (const uint32_t*)stats, w.qinfo, st);
+  if (e != hipSuccess) return hip_fail(e, "rr_flat_search_screened/queries");
+  // the int8 rows through the same scan + exact selection, k' = list_len; a row of dim8 bytes is dim8/2 two-byte elements
+  int rc = flat_search_impl(x8, kDtypeI8, n_rows, dim8 / 2, w.q8, nq, list_len, w.PL, w.IL, 0, w.inner, w.inner_bytes, nullptr, 0, nullptr, stream);
+  if (rc != RR_OK) return rc;
+  e = launch_rescore(xb, xq, dtype, dim, nq, list_len, w.PL, w.IL, w.qinfo, k, D, I, id_offset, exact, route_mask, mask_stride, st);
+  return e == hipSuccess ? RR_OK : hip_fail(e, "rr_flat_search_screened/rescore");
 }
 
 int rr_half_sqnorms(const void* xb, int dtype, int64_t n_rows, int dim, float* out, void* stream) {

@@ -50,6 +50,12 @@ template <> struct Mfma<__bf16> {
   }
 };
 
+// int8 screening copy (rr_flat_search_screened): rows are viewed as pairs of bytes, so a row of D "elements" is 2*D
+// int8 values and every address computation below is the f16 one; only the MFMA opcode (K = 64 bytes per 16-byte lane
+// operand) and the accumulator type differ.  Only flat_scan16_kernel is instantiated for it.
+struct I8Pair { int16_t v; };
+template <> struct Mfma<I8Pair> { typedef s16x8 frag; };
+
 // Inline-asm MFMA: accumulator in VGPRs (the epilogue's VALU reads it there), corpus fragment (A) in VGPRs, query fragment (B) either in AGPRs
 // (block 0) or VGPRs (block 1).  hipcc otherwise keeps part of the resident queries in AGPRs and copies
 // them to VGPRs with v_accvgpr_read before every MFMA (~250 copies per tile).  The accumulate chain
@@ -445,9 +451,15 @@ template <typename T> struct Mfma16Asm;
   };
 RR_MFMA16(_Float16, "v_mfma_f32_16x16x32_f16", f16x8)
 RR_MFMA16(__bf16, "v_mfma_f32_16x16x32_bf16", bf16x8)
+RR_MFMA16(I8Pair, "v_mfma_i32_16x16x64_i8", s16x8)  // i32 accumulators, converted to f32 (exact: |dot| < 2^24 for 2*D <= 1536) before the epilogue
 #undef RR_MFMA16
 
 constexpr int kTicketBatch = 4;  // tiles per dynamic ticket
+
+// LDS ring depth of flat_scan16_kernel.  What must stay in flight per CU is BYTES (~96 KB against the loaded HBM latency:
+// 256 CUs x 96 KB / 2.5 us ~ 9.8 TB/s), so narrow rows need more slots; measured with 3 slots: d=384 streamed 3.8 TB/s.
+// (INFL-1)*(KG+1) <= 63 (vmcnt range) holds for every entry.
+__host__ __device__ constexpr int scan16_slots(int D) { return D >= 640 ? 3 : D == 512 ? 4 : D == 384 ? 6 : D == 256 ? 7 : 13; }
 
 struct LaneState4 {
   float thr[4];
@@ -530,6 +542,8 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   constexpr int NQ = 4 * KS2;        // resident query fragments per wave
   constexpr int NAQ = NQ < 62 ? NQ : 62;  // ... of which live in AGPRs (4*62 = 248)
   constexpr int TILE_BYTES = kTileRows * D * 2;
+  constexpr int NS = scan16_slots(D);  // LDS ring slots; NS - 1 tiles are in flight while one is computed
+  constexpr int INFL = NS - 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
@@ -574,13 +588,13 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   const int nb = __builtin_amdgcn_readfirstlane(
       (int)a.nq <= wave * 64 ? 0 : ((int)a.nq - wave * 64 >= 64 ? 4 : ((int)a.nq - wave * 64 + 15) / 16));
 
-  // L2: |x|^2/2 of the 32 rows of tile ordinal jj -> LDS floats [3*TILE_BYTES + slot*256 ...] (lanes 32..63 duplicate)
+  // L2: |x|^2/2 of the 32 rows of tile ordinal jj -> LDS floats [NS*TILE_BYTES + slot*256 ...] (lanes 32..63 duplicate)
   auto issue_norms = [&](uint32_t jj, int slot_) {
     if (jj >= a.n_tiles) jj = a.n_tiles - 1;
     uint32_t row = (a.tile_first + jj * a.tile_stride) * kTileRows + (lane & 31);
     row = row < a.n_rows ? row : a.n_rows - 1;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.half_sqnorm + row),
-                                     (__attribute__((address_space(3))) void*)(smem + 3 * TILE_BYTES + slot_ * 256), 4, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(smem + NS * TILE_BYTES + slot_ * 256), 4, 0, 0);
   };
   const bool norm_wave = L2 && wave == 1;  // not the ticket wave (wave 0)
 
@@ -592,8 +606,8 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   // tile's own vmcnt wait covers it; lane 0 posts it to LDS before the barrier, every wave reads it after.
   const uint32_t stride = gridDim.x;
   const uint32_t n_tiles = a.n_tiles;
-  const bool dyn = a.tile_counter != nullptr;
-  uint32_t* ticket_lds = (uint32_t*)(smem + 3 * TILE_BYTES + 3 * 256);  // 2 alternating words
+  const bool dyn = NS == 3 && a.tile_counter != nullptr;  // (tickets are wired for the 3-slot ring only)
+  uint32_t* ticket_lds = (uint32_t*)(smem + NS * TILE_BYTES + NS * 256);  // 2 alternating words
   // The atomic returns asynchronously, so its destination must not be a compiler-visible value (hipcc copies such a
   // register right after the asm statement, before the data lands - seen in the ISA).  It returns into the hard-wired
   // accumulator register a255, claimed through clobbers, and is read inside the same asm statement as the covering vmcnt.
@@ -610,14 +624,13 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   uint32_t j = blockIdx.x, j1 = blockIdx.x + stride;
   request_ticket();
   if (j < n_tiles) {
-    const char* g0 = tile_src(j);
-    const char* g1 = tile_src(j1);
-    if (norm_wave) issue_norms(j, 0);
 #pragma unroll
-    for (int kg = 0; kg < KG; ++kg) issue_piece(g0, 0, kg);
-    if (norm_wave) issue_norms(j1, 1);
+    for (int t = 0; t < INFL; ++t) {
+      const char* gt = tile_src(j + t * stride);
+      if (norm_wave) issue_norms(j + t * stride, t);
 #pragma unroll
-    for (int kg = 0; kg < KG; ++kg) issue_piece(g1, 1, kg);
+      for (int kg = 0; kg < KG; ++kg) issue_piece(gt, t, kg);
+    }
   }
 
   // (the first two tiles are already in flight: their HBM latency overlaps the query loads below)
@@ -652,9 +665,10 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   int slot = 0, par = 0, sub = kTicketBatch;
   uint32_t base = 0, dbg_iter = 0;
   while (j < n_tiles) {
-    // queue (oldest first): [norms t] DMA t  ticket [norms t+1] DMA t+1 -> all but the youngest KG (+1 on the norm wave) are done
-    if (norm_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KG + 1) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KG) : "memory");
+    // queue (oldest first): [norms t] DMA t  ticket [norms t+1] DMA t+1 ... -> all but the pieces of the INFL-1 younger tiles
+    // (KG each, +1 on the norm wave) are done
+    if (norm_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((INFL - 1) * (KG + 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((INFL - 1) * KG) : "memory");
     const bool fetch = dyn && sub == kTicketBatch;  // workgroup-uniform: a new batch of kTicketBatch consecutive tiles starts
     if (fetch && wave == 0) {
       uint32_t ticket;
@@ -671,9 +685,9 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
       a.timeline[3 * gridDim.x + blockIdx.x * 64 + (dbg_iter++ & 63)] = j;
     }
     __builtin_amdgcn_s_barrier();
-    int nslot = slot + 2;
-    if (nslot >= 3) nslot -= 3;
-    uint32_t j2 = j1 + stride;
+    int nslot = slot + INFL;
+    if (nslot >= NS) nslot -= NS;
+    uint32_t j2 = j + INFL * stride;
     if (dyn) {
       if (fetch) {
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket_lds[par]);
@@ -732,9 +746,17 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
                        "+v"(acc[1][2]), "+v"(acc[1][3]));
       else
         asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][0]));
+      if (std::is_same<T, I8Pair>::value) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[rb][qb][i] = (float)__float_as_int(acc[rb][qb][i]);
+      }
       if (L2) {
-        const f32x4 h0 = *(const f32x4*)(smem + 3 * TILE_BYTES + slot * 256 + (4 * g) * 4);
-        const f32x4 h1 = *(const f32x4*)(smem + 3 * TILE_BYTES + slot * 256 + (16 + 4 * g) * 4);
+        const f32x4 h0 = *(const f32x4*)(smem + NS * TILE_BYTES + slot * 256 + (4 * g) * 4);
+        const f32x4 h1 = *(const f32x4*)(smem + NS * TILE_BYTES + slot * 256 + (16 + 4 * g) * 4);
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb) {
           acc[0][qb] -= h0;
@@ -752,8 +774,8 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
       for (int kg = 0; kg < KG; ++kg) issue_piece(gn, nslot, kg);
     }
     slot = slot + 1;
-    if (slot >= 3) slot = 0;
-    j = j1;
+    if (slot >= NS) slot = 0;
+    j = dyn ? j1 : j + stride;
     j1 = j2;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory", "a255");  // no LDS-DMA (or ticket) may outlive the workgroup
@@ -1272,7 +1294,7 @@ static hipError_t launch_scan_v(const ScanArgs& a, int grid, hipStream_t st) {
 
 template <typename T, int D, bool DENSE, bool NT = false, bool L2 = false>
 static hipError_t launch_scan16(const ScanArgs& a, int grid, hipStream_t st) {
-  const size_t lds = 3 * (size_t)kTileRows * D * 2 + 3 * 256 + 16;  // ring + L2 norm slots + ticket words
+  const size_t lds = scan16_slots(D) * ((size_t)kTileRows * D * 2 + 256) + 16;  // ring + L2 norm slots + ticket words
   hipError_t e = hipFuncSetAttribute((const void*)flat_scan16_kernel<T, D, DENSE, NT, L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((flat_scan16_kernel<T, D, DENSE, NT, L2>), dim3(grid), dim3(256), lds, st, a);
@@ -1336,8 +1358,23 @@ static hipError_t launch_scan_d(const ScanArgs& a, int D, bool dense, int grid, 
   }
 }
 
+// int8 screening scan: D = bytes per row / 2
+static hipError_t launch_scan_i8(const ScanArgs& a, int D, bool dense, int grid, hipStream_t st) {
+  const bool nt = (size_t)a.n_rows * D * 2 > kNtThresholdBytes;
+#define RR_I8_CASE(D_)                                                            \
+  case D_:                                                                        \
+    if (dense) return launch_scan16<I8Pair, D_, true, false>(a, grid, st);        \
+    return nt ? launch_scan16<I8Pair, D_, false, true>(a, grid, st) : launch_scan16<I8Pair, D_, false, false>(a, grid, st);
+  switch (D) {
+    RR_I8_CASE(128) RR_I8_CASE(256) RR_I8_CASE(384) RR_I8_CASE(512) RR_I8_CASE(640) RR_I8_CASE(768)
+    default: return hipErrorInvalidValue;
+  }
+#undef RR_I8_CASE
+}
+
 hipError_t launch_flat_scan(const ScanArgs& a, int dtype, int D, bool dense, int grid, hipStream_t st) {
   read_variant_env();
+  if (dtype == kDtypeI8) return a.half_sqnorm ? hipErrorNotSupported : launch_scan_i8(a, D, dense, grid, st);
   if (a.half_sqnorm && (D > kMaxResidentDim || g_scan_variant == 3)) return hipErrorNotSupported;  // L2: resident-query kernel only
   if (scan_queries_per_launch(D) == 128) {  // 768 < D <= 1536: 32 resident queries per wave, half-tile ring
     if (dtype == RR_DTYPE_F16) return launch_scan_half_resident<_Float16>(a, D, dense, grid, st);

@@ -20,6 +20,7 @@ constexpr int kSelectCap = 8192;       // u64 keys sorted in LDS by the select k
 constexpr int kSampleRows = 8192;      // bootstrap sample rows (256 tiles)
 constexpr int kDenseMaxRows = 8192;    // corpora up to this size take the dense path
 constexpr int kChunkGrowth = 8;
+constexpr int kDtypeI8 = 2;            // internal: the int8 screening copy (after RR_DTYPE_F16 / RR_DTYPE_BF16)
 
 // ---- total order on candidates: score descending, then id ascending ---------------------
 // key = ord(score) << 32 | (0xFFFFFFFF - id); larger key = better. key 0 = empty slot

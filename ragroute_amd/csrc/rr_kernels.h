@@ -58,6 +58,14 @@ hipError_t launch_rows_to_half(const float* x, int64_t n, int64_t d, int64_t ld_
 hipError_t launch_half_sqnorms(const void* xb, int dtype, int64_t n, int dim, float* out, hipStream_t st);
 hipError_t launch_centroid(const void* xb, int dtype, int64_t n, int dim, int d, float* out, hipStream_t st);
 
+// screen.hip (int8 screening copy + exact re-scoring)
+hipError_t launch_screen_build(const void* xb, int dtype, int64_t n, int dim, int8_t* x8, int dim8, uint32_t* stats, hipStream_t st);
+hipError_t launch_screen_queries(const void* xq, int dtype, int nq, int dim, int8_t* q8, int dim8, const uint32_t* stats, float* qinfo,
+                                 hipStream_t st);
+hipError_t launch_rescore(const void* xb, const void* xq, int dtype, int dim, int nq, int L, const float* PL, const int64_t* IL,
+                          const float* qinfo, int k, float* D, int64_t* I, int64_t id_offset, uint8_t* exact, const uint8_t* mask,
+                          int64_t mask_stride, hipStream_t st);
+
 // router.hip
 hipError_t launch_router_mlp(const rr_router_weights* w, const float* xq, int nq, float* logits, uint8_t* mask,
                              hipStream_t st);

@@ -8,6 +8,7 @@
 // bitonic sort of 64-bit order keys in LDS.
 #include "rr_common.h"
 #include "rr_kernels.h"
+#include "rr_sort.h"
 
 namespace rr {
 
@@ -17,30 +18,6 @@ __device__ __forceinline__ float next_below(float x) {
   uint32_t b = __float_as_uint(x);
   if ((b & 0x7FFFFFFFu) == 0) return __uint_as_float(0x80000001u);
   return __uint_as_float((b & 0x80000000u) ? b + 1 : b - 1);
-}
-
-__device__ __forceinline__ int pow2_ceil(int n) {
-  int p = 1;
-  while (p < n) p <<= 1;
-  return p;
-}
-
-// descending bitonic sort of n (power of two) u64 keys in LDS by the whole workgroup
-__device__ void bitonic_sort_desc(uint64_t* s, int n) {
-  const int tid = threadIdx.x, nt = blockDim.x;
-  for (int k2 = 2; k2 <= n; k2 <<= 1) {
-    for (int j = k2 >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < n; i += nt) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const uint64_t x = s[i], y = s[ixj];
-          const bool desc = (i & k2) == 0;
-          if ((x < y) == desc) { s[i] = y; s[ixj] = x; }
-        }
-      }
-      __syncthreads();
-    }
-  }
 }
 
 __global__ void init_state_kernel(SelectArgs a) {

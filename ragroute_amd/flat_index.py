@@ -49,6 +49,10 @@ class FlatIndex:
     as data_source.py:196-203 does for the wikipedia corpora) or "l2" (squared L2 distances, nearest first: the role of
     faiss.IndexFlatL2; d <= 768).
     dtype : "fp16" or "bf16" storage/MFMA input type; scores accumulate in f32.
+
+    build_screen() adds an int8 screening copy (ip / cosine, d <= 1536): searches then stream half the bytes and return the
+    same exact top-k, proven per query by a quantisation-error bound; a batch whose proof fails is repeated on the
+    f16/bf16 rows (counted in `screen_fallbacks`).
     """
 
     def __init__(self, d, metric="ip", dtype="fp16", device=None):
@@ -70,6 +74,10 @@ class FlatIndex:
         if metric == "l2" and self.dim > 768:
             raise _lib.RagrouteHipError("the L2 metric supports d <= 768 in this build")
         self._ws = {}
+        self._x8 = self._x8_stats = None   # int8 screening copy (build_screen)
+        self._ws_screen = {}
+        self.screen_list = 512
+        self.screen_fallbacks = 0
 
     # -- storage -----------------------------------------------------------------------------
     def reserve(self, n):
@@ -98,6 +106,7 @@ class FlatIndex:
                                             self.dim, int(self.metric == "cosine"), _stream_ptr()), "rr_rows_to_half")
                 del part
         self.ntotal += n
+        self._x8 = self._x8_stats = None  # one scale for the whole corpus: the screening copy is rebuilt, not appended to
         self._refresh_norms()
 
     def _refresh_norms(self):
@@ -114,7 +123,62 @@ class FlatIndex:
             raise ValueError("adopt() needs a contiguous device matrix [n, rr_padded_dim(d)] of the index dtype")
         self._xb = xb_dev
         self.ntotal = int(xb_dev.shape[0] if ntotal is None else ntotal)
+        self._x8 = self._x8_stats = None
         self._refresh_norms()
+
+    def build_screen(self, list_len=None):
+        """Build the int8 screening copy of the current corpus (+50 % HBM).  list_len: rows per query that are re-scored
+        exactly (k <= list_len <= 1024; default max(512, 16 k) capped at 1024)."""
+        if self.metric == "l2":
+            raise _lib.RagrouteHipError("the int8 screening copy serves the ip / cosine metrics only")
+        dim8 = lib().rr_screen_dim(self.dim)
+        if dim8 < 0:
+            raise _lib.RagrouteHipError("the int8 screening copy needs d <= 1536")
+        if list_len is not None:
+            self.screen_list = int(list_len)
+        self._x8 = torch.empty((max(1, self.ntotal), dim8), dtype=torch.int8, device=self.device)
+        self._x8_stats = torch.zeros(8, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().rr_screen_build(self._xb.data_ptr(), _RR_DTYPE[self.dtype], self.ntotal, self.dim, self._x8.data_ptr(),
+                                        self._x8_stats.data_ptr(), _stream_ptr()), "rr_screen_build")
+        return self
+
+    def search_screened(self, xq_half, k, id_offset=0, out=None, route_mask=None, list_len=None):
+        """Device-to-device search through the int8 screening copy: (D, I, exact) CUDA tensors; exact[q] == 1 where the result
+        is proven to be the exact top-k.  No host sync; search_prepared() wraps this with the check and the fallback."""
+        if self._x8 is None:
+            raise _lib.RagrouteHipError("build_screen() has not been called (or the corpus changed since)")
+        nq = xq_half.shape[0]
+        L = int(list_len if list_len is not None else min(_lib.RR_MAX_K, max(self.screen_list, 16 * k)))
+        L = max(L, k)
+        key = (k, L, nq)
+        ws = self._ws_screen.get(key)
+        if ws is None:
+            nbytes = lib().rr_flat_search_screened_workspace_bytes(k, L, nq, self.dim)
+            if nbytes == 0:
+                raise ValueError(f"need 1 <= k <= list_len <= {_lib.RR_MAX_K}, got k={k}, list_len={L}")
+            self._ws_screen = {key: torch.empty(nbytes, dtype=torch.uint8, device=self.device)}
+            ws = self._ws_screen[key]
+        if out is None:
+            D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        else:
+            D, I = out
+        exact = torch.empty(nq, dtype=torch.uint8, device=self.device)
+        mptr, mstride = self._mask_args(route_mask, nq)
+        check(lib().rr_flat_search_screened(self._xb.data_ptr(), _RR_DTYPE[self.dtype], self._x8.data_ptr(), self._x8_stats.data_ptr(),
+                                            self.ntotal, self.dim, xq_half.data_ptr(), nq, k, L, D.data_ptr(), I.data_ptr(), id_offset,
+                                            exact.data_ptr(), ws.data_ptr(), ws.numel(), mptr, mstride, _stream_ptr()),
+              "rr_flat_search_screened")
+        return D, I, exact
+
+    @staticmethod
+    def _mask_args(route_mask, nq):
+        if route_mask is None:
+            return None, 0
+        if route_mask.dtype not in (torch.bool, torch.uint8) or route_mask.dim() != 1 or route_mask.shape[0] != nq or not route_mask.is_cuda:
+            raise ValueError("route_mask must be a bool/uint8 CUDA vector with one entry per query")
+        return route_mask.data_ptr(), route_mask.stride(0)
 
     def centroid(self):
         """float32 CUDA vector [d]: mean of the stored rows (the router's centroid feature, router.py:147-151)."""
@@ -158,17 +222,20 @@ class FlatIndex:
         if xq_half.dtype != self._xb.dtype or xq_half.dim() != 2 or xq_half.shape[1] != self.dim or not xq_half.is_contiguous():
             raise ValueError("search_prepared() needs contiguous [nq, dim] queries of the index dtype")
         nq = xq_half.shape[0]
+        if self._x8 is not None and nq > 0:
+            # screened search; the proof flags are the one host read of this path
+            D, I, exact = self.search_screened(xq_half, k, id_offset, out, route_mask)
+            if bool(exact.all()):
+                return D, I
+            self.screen_fallbacks += 1
+            out = (D, I)
         ws = self._workspace(k)
         if out is None:
             D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
             I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         else:
             D, I = out
-        mptr, mstride = None, 0
-        if route_mask is not None:
-            if route_mask.dtype not in (torch.bool, torch.uint8) or route_mask.dim() != 1 or route_mask.shape[0] != nq or not route_mask.is_cuda:
-                raise ValueError("route_mask must be a bool/uint8 CUDA vector with one entry per query")
-            mptr, mstride = route_mask.data_ptr(), route_mask.stride(0)
+        mptr, mstride = self._mask_args(route_mask, nq)
         if self.metric == "l2":
             check(lib().rr_flat_search_l2(self._xb.data_ptr(), self._hn.data_ptr() if self._hn is not None else None,
                                           _RR_DTYPE[self.dtype], self.ntotal, self.dim, xq_half.data_ptr(), nq, k, D.data_ptr(),
