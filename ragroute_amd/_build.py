@@ -17,6 +17,8 @@ def build(force=False, verbose=False):
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-o", LIB_PATH] + srcs
     if os.environ.get("RR_ABLATION_VARIANTS"):
         cmd.insert(1, "-DRR_ABLATION_VARIANTS")
+    if os.environ.get("RR_EXTRA_DEFINES"):  # development A/B builds, e.g. "-DRR_DMA_SCHED=1"
+        cmd[1:1] = os.environ["RR_EXTRA_DEFINES"].split()
     if os.environ.get("RR_LIB_SUFFIX"):
         cmd[cmd.index("-o") + 1] = LIB_PATH.replace(".so", os.environ["RR_LIB_SUFFIX"] + ".so")
     res = subprocess.run(cmd, capture_output=True, text=True)
