@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, "/root/reference")
 
-from tests.util import synth_medrag_corpus, synth_router_case  # noqa: E402
+from tests.util import flat_golden_inputs, synth_medrag_corpus, synth_router_case  # noqa: E402
 
 
 def _stub_transport():
@@ -186,7 +186,24 @@ def golden_data_source_glue():
     json.dump(out, open(os.path.join(HERE, "data_source_glue.json"), "w"), indent=1)
 
 
+def golden_flat_search():
+    """index.search itself is third-party faiss (absent here), so there is no reference output to record: this fixture is an
+    INDEPENDENT statement of the flat-IP semantics (f64 numpy matmul, (score desc, id asc) order) that both the C oracle and
+    the HIP path are checked against.  It does not pin faiss's f32 summation order ("parity unpinned")."""
+    k, out = 32, {}
+    for case in ("gauss", "int", "cosine"):
+        xb, xq = flat_golden_inputs(case)
+        S = xq.astype(np.float64) @ xb.astype(np.float64).T
+        ids = np.tile(np.arange(S.shape[1]), (S.shape[0], 1))
+        order = np.lexsort((ids, -S), axis=1)[:, :k]
+        out[case + "_I"] = order.astype(np.int64)
+        out[case + "_D"] = np.take_along_axis(S, order, axis=1)
+        out[case + "_gap"] = np.partition(S, -k - 1, axis=1)[:, -k - 1]   # (k+1)-th best score: how well separated the set is
+    np.savez(os.path.join(HERE, "flat_search.npz"), **out)
+
+
 if __name__ == "__main__":
+    golden_flat_search()
     _stub_transport()
     golden_rerank()
     golden_router()

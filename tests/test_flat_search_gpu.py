@@ -267,3 +267,21 @@ def test_l2_metric_bf16_and_single_query(gpu):
     D, I = _index(gpu, xb, 640, metric="l2", dtype="bf16").search(xq, 10)
     Dref, Iref = O.flat_search_l2(xb, xq, 10)
     assert np.array_equal(I, Iref) and np.array_equal(D, Dref)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("case", ["gauss", "int", "cosine"])
+def test_committed_fixture(gpu, case, dtype):
+    """The HIP path against tests/golden/flat_search.npz (f64 numpy statement, generated by tests/golden/make_golden.py)."""
+    import os
+    from tests.util import flat_golden_inputs
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "flat_search.npz"))
+    xb, xq = flat_golden_inputs(case)
+    if dtype == "bf16" and case != "int":
+        pytest.skip("the fixture's non-integer inputs are fp16-rounded")
+    D, I = _index(gpu, xb, 768, dtype=dtype).search(xq, 32)
+    assert np.array_equal(I, G[case + "_I"])
+    if case == "int":
+        assert np.array_equal(D.astype(np.float64), G["int_D"])
+    else:
+        assert np.allclose(D, G[case + "_D"], atol=1e-3, rtol=0)

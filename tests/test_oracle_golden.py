@@ -103,3 +103,17 @@ def test_merge_topk_oracle():
     assert np.all(np.diff(Da, axis=1) >= 0)
     Dp, Ip = O.merge_topk(D[:, :3], np.full((5, 3), -1, np.int64), 4, True)
     assert (Ip == -1).all() and np.isneginf(Dp).all()
+
+
+@pytest.mark.parametrize("case", ["gauss", "int", "cosine"])
+def test_flat_search_matches_committed_fixture(case):
+    """tests/golden/flat_search.npz: f64 numpy statement of flat-IP top-k on seeded fp16-rounded inputs."""
+    from tests.util import flat_golden_inputs
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "flat_search.npz"))
+    xb, xq = flat_golden_inputs(case)
+    D, I = O.flat_search_ip(xb, xq, 32)
+    if case == "int":
+        assert np.array_equal(I, G["int_I"]) and np.array_equal(D.astype(np.float64), G["int_D"])
+    else:
+        assert np.array_equal(I, G[case + "_I"])           # f32 summation error << the score gaps of this fixture
+        assert np.allclose(D, G[case + "_D"], atol=1e-3, rtol=0)

@@ -86,3 +86,21 @@ def synth_medrag_corpus(seed, n=600, d=768):
     metadatas = [{"index": i % per, "source": books[min(i // per, len(books) - 1)]} for i in range(n)]
     chunks = {b: [{"id": f"{b}_{j}", "title": f"title {b} {j}", "content": f"content of {b} chunk {j}"} for j in range(per + n)] for b in books}
     return xb, metadatas, chunks
+
+
+def flat_golden_inputs(case):
+    """Seeded inputs of the flat-search fixture tests/golden/flat_search.npz (N=4096, d=768, B=8, k=32,
+    fp16-rounded).  Only the expected outputs are stored; the inputs are regenerated from the seed (numpy's PCG64 streams
+    are stable across versions)."""
+    rng = np.random.default_rng({"gauss": 101, "int": 102, "cosine": 103}[case])
+    n, d, nq = 4096, 768, 8
+    if case == "int":
+        return int_data(rng, n, d), int_data(rng, nq, d)
+    xb = rng.standard_normal((n, d)).astype(np.float32)
+    xq = rng.standard_normal((nq, d)).astype(np.float32)
+    if case == "cosine":   # normalise in f64, then round to the stored precision: what the index holds
+        xb = (xb / np.linalg.norm(xb.astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
+        xq = (xq / np.linalg.norm(xq.astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
+    else:
+        xb /= np.float32(np.sqrt(d))
+    return half_round(xb), half_round(xq)
