@@ -172,7 +172,7 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
   hipError_t e;
 #define RR_CHECK(call, what) do { e = (call); if (e != hipSuccess) return hip_fail(e, what); } while (0)
 
-  const int qpl = scan_queries_per_launch(dim);  // 256, or 128 where only 32 queries per wave stay resident
+  const int qpl = scan_queries_per_launch(dim, nq);  // 256, or 128 where only 32 queries per wave stay resident and the batch is small
   for (int qb = 0; qb < nq; qb += qpl) {
     const int nqb = nq - qb < qpl ? nq - qb : qpl;
     const char* xq_b = (const char*)xq + (size_t)qb * dim * 2;
