@@ -37,7 +37,7 @@ int rr_device_cus(void);
 
 /* Row width (in elements) the scan kernel needs for embedding dimension d: the corpus and the
  * queries must be stored with this leading dimension, zero padded: 128..768 in steps of 128 (queries stay
- * register-resident), above that the next multiple of 64 up to 8192 (generic kernel).  <0 if d is unsupported. */
+ * register-resident), 896 / 1024 / 1280 / 1536, above that the next multiple of 128 up to 8192 (wide-row kernel).  <0 if d is unsupported. */
 int rr_padded_dim(int d);
 
 /* In-place row-wise L2 normalisation of an f32 matrix, zero-norm rows left unchanged.

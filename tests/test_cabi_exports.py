@@ -28,7 +28,7 @@ def test_version_and_padded_dim():
     L = _lib.lib()
     assert L.rr_version() >= 100
     assert [L.rr_padded_dim(d) for d in (1, 100, 128, 129, 768)] == [128, 128, 128, 256, 768]
-    assert [L.rr_padded_dim(d) for d in (769, 1024, 1100, 1537, 4096)] == [896, 1024, 1280, 1600, 4096]
+    assert [L.rr_padded_dim(d) for d in (769, 1024, 1100, 1537, 4096)] == [896, 1024, 1280, 1664, 4096]  # above 1536: multiples of 128 (wide-row kernel)
     assert L.rr_padded_dim(8193) == -2 and L.rr_padded_dim(0) == -1
 
 
