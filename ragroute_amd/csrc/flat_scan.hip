@@ -1362,12 +1362,19 @@ __device__ __forceinline__ void query_load_frag(F& dst, uint32_t lane_off, const
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(lane_off), "s"(sbase), "n"(imm) : "memory");
 }
 
+// (Carrying the fragment ring across K steps - 4 slots, the barrier moved to fragment 24 of the step before - measured 3.53 vs
+// 3.66 TB/s: no gain, like the same experiment on flat_scan16_kernel; not kept.)
+template <int N, typename F>
+__device__ __forceinline__ void vm_wait_tied8(F& r0, F& r1, F& r2, F& r3, F& r4, F& r5, F& r6, F& r7) {
+  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "n"(N) : "memory");
+}
 template <typename T, bool DENSE>
 __global__ __launch_bounds__(256, 1) void flat_scan_wide_kernel(const ScanArgs a, const int D) {
   typedef typename Mfma<T>::frag frag;
   constexpr int NT = 8;                    // 32-row tiles per group
   constexpr int STEP_BYTES = NT * 4096;    // one K step of one group in LDS
   constexpr int NS = 3;
+  constexpr int LEAD = NS - 1;             // K steps the DMA stream runs ahead
   constexpr int NF = 4 * NT;               // A fragments per K step: (tile, s2, rb)
   constexpr int NB = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1439,6 +1446,13 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_kernel(const ScanArgs a
     e[1][0] = read_acc_fixed<R + 16>(); e[1][1] = read_acc_fixed<R + 20>(); e[1][2] = read_acc_fixed<R + 24>(); e[1][3] = read_acc_fixed<R + 28>();
   };
   frag q[2][4][2];                         // [buffer][query block][k slice]
+  // The query loads are asynchronous asm: their destination registers must have LANDED before any point where hipcc may
+  // copy them (it inserts v_mov copies of loop-carried values at loop back-edges).  So the wait for the queries of step
+  // s+1 closes step s, and the statement names the registers as in/out operands: every later use or copy follows it.
+  auto queries_landed = [&](auto buf_tag) {
+    constexpr int B = decltype(buf_tag)::value;
+    vm_wait_tied8<NT>(q[B][0][0], q[B][0][1], q[B][1][0], q[B][1][1], q[B][2][0], q[B][2][1], q[B][3][0], q[B][3][1]);
+  };
   auto load_queries = [&](int buf, int kg) {
     const char* sb = (const char*)a.xq + (size_t)kg * 128;
 #pragma unroll
@@ -1448,22 +1462,27 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_kernel(const ScanArgs a
     }
   };
   if (grp < n_groups) {
-    // prologue, in the steady-state queue order: DMA(0) | q(0), DMA(1)
+    // prologue, in the steady-state queue order: DMA(0) [, DMA(1)] | q(0), DMA(LEAD-1)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) issue_piece(dgrp, dkg, dslot, t);
-    dma_advance();
+    for (int sidx = 0; sidx < LEAD - 1; ++sidx) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) issue_piece(dgrp, dkg, dslot, t);
+      dma_advance();
+    }
     load_queries(0, 0);
 #pragma unroll
     for (int t = 0; t < NT; ++t) issue_piece(dgrp, dkg, dslot, t);
     dma_advance();
+    queries_landed(std::integral_constant<int, 0>{});   // only DMA(LEAD-1) may still be in flight
   }
+
   int slot = 0;   // accumulator of (tile t, row block rb, query block qb): a[16 (2t + rb) + 4 qb ..+3]
   while (grp < n_groups) {
     for (int kg = 0; kg < KG; kg += 2) {
       auto step = [&](auto buf_tag, auto first_tag, int kgs) {
         constexpr int P = decltype(buf_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT) : "memory");
+        // (this step's queries and, older in the queue, its slab pieces were waited for when the previous step closed)
         __builtin_amdgcn_s_barrier();
         {
           int nkg = kgs + 1;
@@ -1501,6 +1520,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_kernel(const ScanArgs a
         }
         dma_advance();
         if (++slot == NS) slot = 0;
+        queries_landed(std::integral_constant<int, 1 - P>{});  // queue: ... q(s+1) | DMA(s+LEAD): NT pieces may remain
       };
       if (kg == 0) step(std::integral_constant<int, 0>{}, std::true_type{}, kg);
       else step(std::integral_constant<int, 0>{}, std::false_type{}, kg);
