@@ -85,7 +85,7 @@ int rr_flat_search(const void* d_xb, int dtype, int64_t n_rows, int dim, const v
 /* The same search under the squared-L2 metric (the role of faiss.IndexFlatL2: the reference's index files decide the metric,
  * data_source.py:71; its wikipedia merge keeps the LOWEST scores, rerank.py:30, i.e. treats scores as distances).  Returns
  * the k nearest rows, nearest first, d_D = |q - x|^2, ties by ascending id, padding (+inf, -1).
- *   d_half_sqnorm  device f32 [n_rows]: |x|^2 / 2 of every stored row (rr_half_sqnorms).  dim <= 768 in this build. */
+ *   d_half_sqnorm  device f32 [n_rows]: |x|^2 / 2 of every stored row (rr_half_sqnorms). */
 int rr_flat_search_l2(const void* d_xb, const float* d_half_sqnorm, int dtype, int64_t n_rows, int dim, const void* d_xq,
                       int nq, int k, float* d_D, int64_t* d_I, int64_t id_offset, void* d_ws, size_t ws_bytes,
                       const uint8_t* d_route_mask, int64_t mask_stride, void* stream);

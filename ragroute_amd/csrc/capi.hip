@@ -238,7 +238,6 @@ int rr_flat_search_l2(const void* xb, const float* half_sqnorm, int dtype, int64
                       float* D, int64_t* I, int64_t id_offset, void* ws, size_t ws_bytes, const uint8_t* route_mask,
                       int64_t mask_stride, void* stream) {
   if (!half_sqnorm && n_rows > 0) return fail(RR_ERR_INVALID, "rr_flat_search_l2: null half_sqnorm%s");
-  if (dim > rr::kMaxResidentDim) return fail(RR_ERR_UNSUPPORTED, "rr_flat_search_l2: the L2 metric needs dim <= 768 in this build%s");
   // an empty index has no norms to pass; any non-null marker selects the L2 finalize (padding +inf) and is never dereferenced
   static const float kEmpty = 0.f;
   return flat_search_impl(xb, dtype, n_rows, dim, xq, nq, k, D, I, id_offset, ws, ws_bytes, route_mask, mask_stride,

@@ -1368,7 +1368,7 @@ template <int N, typename F>
 __device__ __forceinline__ void vm_wait_tied8(F& r0, F& r1, F& r2, F& r3, F& r4, F& r5, F& r6, F& r7) {
   asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "n"(N) : "memory");
 }
-template <typename T, bool DENSE>
+template <typename T, bool DENSE, bool L2 = false>
 __global__ __launch_bounds__(256, 1) void flat_scan_wide_kernel(const ScanArgs a, const int D) {
   typedef typename Mfma<T>::frag frag;
   constexpr int NT = 8;                    // 32-row tiles per group
@@ -1535,6 +1535,20 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_kernel(const ScanArgs a
         if (j < n_tiles) {
           f32x4 e[2][4];
           read_tile(std::integral_constant<int, 32 * t>{}, e);
+          if (L2) {  // rank by q.x - |x|^2/2: the lane's 2 x 4 rows of this tile (rows past the end are filtered by id later)
+            const uint32_t r0 = (a.tile_first + j * a.tile_stride) * kTileRows + 4 * g;
+            f32x4 h0, h1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              h0[i] = a.half_sqnorm[r0 + i < a.n_rows ? r0 + i : a.n_rows - 1];
+              h1[i] = a.half_sqnorm[r0 + 16 + i < a.n_rows ? r0 + 16 + i : a.n_rows - 1];
+            }
+#pragma unroll
+            for (int qb = 0; qb < 4; ++qb) {
+              e[0][qb] -= h0;
+              e[1][qb] -= h1;
+            }
+          }
           tile_epilogue16<DENSE, 4>(a, st, e, j, lane, wave);
         }
       });
@@ -1595,20 +1609,21 @@ static hipError_t launch_scan_tall(const ScanArgs& a, int D, bool dense, int gri
 }
 template <typename T>
 static hipError_t launch_scan_generic(const ScanArgs& a, int D, bool dense, int grid, hipStream_t st) {
-  if (g_generic_tall == 16 && D % 128 == 0) {
+  if ((g_generic_tall == 16 || a.half_sqnorm) && D % 128 == 0) {
     const size_t lds = 3 * 8 * 4096;
     hipError_t e;
-    if (dense) {
-      e = hipFuncSetAttribute((const void*)flat_scan_wide_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL((flat_scan_wide_kernel<T, true>), dim3(grid), dim3(256), lds, st, a, D);
-    } else {
-      e = hipFuncSetAttribute((const void*)flat_scan_wide_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL((flat_scan_wide_kernel<T, false>), dim3(grid), dim3(256), lds, st, a, D);
-    }
+#define RR_LAUNCH_W(DENSE_, L2_)                                                                                             \
+  {                                                                                                                         \
+    e = hipFuncSetAttribute((const void*)flat_scan_wide_kernel<T, DENSE_, L2_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return e;                                                                                          \
+    hipLaunchKernelGGL((flat_scan_wide_kernel<T, DENSE_, L2_>), dim3(grid), dim3(256), lds, st, a, D);                     \
+  }
+    if (a.half_sqnorm) { if (dense) RR_LAUNCH_W(true, true) else RR_LAUNCH_W(false, true) }
+    else { if (dense) RR_LAUNCH_W(true, false) else RR_LAUNCH_W(false, false) }
+#undef RR_LAUNCH_W
     return hipGetLastError();
   }
+  if (a.half_sqnorm) return hipErrorNotSupported;
   if (g_generic_tall == 8) return launch_scan_tall<T, 8>(a, D, dense, grid, st);
   if (g_generic_tall) return launch_scan_tall<T, 4>(a, D, dense, grid, st);
   // two workgroups per CU (<= 256 registers per lane, 16 KB LDS): thread-level parallelism hides the L2 / barrier latency
@@ -1637,7 +1652,7 @@ static bool half_resident_dim(int D) { return D == 896 || D == 1024 || D == 1280
 int scan_queries_per_launch(int D, int nq) {
   read_variant_env();
   if (g_scan_variant == 3) return 256;
-  return (half_resident_dim(D) && nq < g_wide_min_queries) ? 128 : 256;
+  return (half_resident_dim(D) && nq < g_wide_min_queries) ? 128 : 256;  // (an L2 search at these dims still works in 128-query blocks: each goes to the wide-row kernel)
 }
 
 // candidate buffers per (workgroup, query) of the kernel that will serve this dim
@@ -1742,8 +1757,8 @@ static hipError_t launch_scan_i8(const ScanArgs& a, int D, bool dense, int grid,
 hipError_t launch_flat_scan(const ScanArgs& a, int dtype, int D, bool dense, int grid, hipStream_t st) {
   read_variant_env();
   if (dtype == kDtypeI8) return a.half_sqnorm ? hipErrorNotSupported : launch_scan_i8(a, D, dense, grid, st);
-  if (a.half_sqnorm && (D > kMaxResidentDim || g_scan_variant == 3)) return hipErrorNotSupported;  // L2: resident-query kernel only
-  if (g_scan_variant != 3 && half_resident_dim(D) && (int)a.nq >= g_wide_min_queries && g_generic_tall == 16) {
+  if (a.half_sqnorm && g_scan_variant == 3) return hipErrorNotSupported;  // L2: the resident-query and wide-row kernels only
+  if (g_scan_variant != 3 && half_resident_dim(D) && (((int)a.nq >= g_wide_min_queries && g_generic_tall == 16) || a.half_sqnorm)) {
     // more than 128 queries: one pass of the wide-row kernel beats two passes of the half-resident one
     if (dtype == RR_DTYPE_F16) return launch_scan_generic<_Float16>(a, D, dense, grid, st);
     if (dtype == RR_DTYPE_BF16) return launch_scan_generic<__bf16>(a, D, dense, grid, st);

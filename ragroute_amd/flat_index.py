@@ -47,7 +47,7 @@ class FlatIndex:
 
     metric: "ip" (reference behaviour), "cosine" (rows and queries L2-normalised on ingest/search, i.e. normalize_L2 + IP
     as data_source.py:196-203 does for the wikipedia corpora) or "l2" (squared L2 distances, nearest first: the role of
-    faiss.IndexFlatL2; d <= 768).
+    faiss.IndexFlatL2).
     dtype : "fp16" or "bf16" storage/MFMA input type; scores accumulate in f32.
 
     build_screen() adds an int8 screening copy (ip / cosine, d <= 1536): searches then stream half the bytes and return the
@@ -71,8 +71,6 @@ class FlatIndex:
         self.ntotal = 0
         self._xb = torch.empty((0, self.dim), dtype=_TORCH_DTYPE[dtype], device=self.device)
         self._hn = None  # |x|^2/2 per row (metric "l2")
-        if metric == "l2" and self.dim > 768:
-            raise _lib.RagrouteHipError("the L2 metric supports d <= 768 in this build")
         self._ws = {}
         self._x8 = self._x8_stats = None   # int8 screening copy (build_screen)
         self._ws_screen = {}

@@ -185,7 +185,8 @@ def test_randomised_shapes(gpu):
         assert np.array_equal(D, Dref), (it, n, d, nq, k, dtype)
 
 
-@pytest.mark.parametrize("n,nq,k,d", [(5000, 40, 10, 768), (90_000, 256, 32, 768), (30_000, 7, 100, 200), (33, 3, 50, 128)])
+@pytest.mark.parametrize("n,nq,k,d", [(5000, 40, 10, 768), (90_000, 256, 32, 768), (30_000, 7, 100, 200), (33, 3, 50, 128),
+                                      (40_000, 200, 10, 1024), (40_000, 5, 10, 1024), (20_000, 9, 10, 2048), (300, 3, 10, 4096)])
 def test_l2_metric_bit_exact_on_integer_data(gpu, n, nq, k, d):
     """Squared-L2 flat search (faiss.IndexFlatL2 contract): nearest first, ties by ascending id, (+inf,-1) padding."""
     from oracle import oracle as O
