@@ -183,7 +183,7 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
     memset(&s, 0, sizeof(s));
     s.thr = w.thr; s.list = w.list; s.list_cnt = w.list_cnt; s.tile_counters = w.tile_counters; s.cand = w.cand; s.cand_cnt = w.cand_cnt;
     s.dense = w.dense; s.dense_ld = kSampleRows; s.n_rows = (uint32_t)n_rows; s.nq = (uint32_t)nqb;
-    s.nbuf = (uint32_t)grid * (uint32_t)(dtype == kDtypeI8 ? 4 : scan_bufs_per_wg(dim)); s.list_ld = kMaxK; s.cap = cap; s.k = k;
+    s.nbuf = (uint32_t)grid * (uint32_t)(dtype == kDtypeI8 ? 4 : scan_bufs_per_wg(dim, half_sqnorm != nullptr)); s.list_ld = kMaxK; s.cap = cap; s.k = k;
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     a.xb = xb; a.xq = xq_b; a.thr = w.thr; a.cand = w.cand; a.cand_cnt = w.cand_cnt; a.scratch = w.scratch;

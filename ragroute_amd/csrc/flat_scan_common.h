@@ -1,0 +1,323 @@
+// Device helpers shared by the scan kernels (flat_scan.hip: production kernels; flat_scan_dev.hip: measured alternatives
+// kept for A/B runs): MFMA wrappers, asm LDS / wait primitives, the exact wave-level compaction and the tile epilogues.
+#pragma once
+#include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "rr_common.h"
+#include "rr_kernels.h"
+
+namespace rr {
+
+
+template <typename T> struct Mfma;
+template <> struct Mfma<_Float16> {
+  typedef f16x8 frag;
+  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mfma<__bf16> {
+  typedef bf16x8 frag;
+  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+// int8 screening copy (rr_flat_search_screened): rows are viewed as pairs of bytes, so a row of D "elements" is 2*D
+// int8 values and every address computation below is the f16 one; only the MFMA opcode (K = 64 bytes per 16-byte lane
+// operand) and the accumulator type differ.  Only flat_scan16_kernel is instantiated for it.
+struct I8Pair { int16_t v; };
+template <> struct Mfma<I8Pair> { typedef s16x8 frag; };
+
+// Inline-asm MFMA: accumulator in VGPRs (the epilogue's VALU reads it there), corpus fragment (A) in VGPRs, query fragment (B) either in AGPRs
+// (block 0) or VGPRs (block 1).  hipcc otherwise keeps part of the resident queries in AGPRs and copies
+// them to VGPRs with v_accvgpr_read before every MFMA (~250 copies per tile).  The accumulate chain
+// (srcC == vDst) needs no wait states; the reader after the chain is fenced by mfma_drain().
+template <typename T> struct MfmaAsm;
+template <> struct MfmaAsm<_Float16> {
+  static __device__ __forceinline__ void first_a(f32x16& c, f16x8 a, f16x8 b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "a"(b));
+  }
+  static __device__ __forceinline__ void acc_a(f32x16& c, f16x8 a, f16x8 b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+  }
+  static __device__ __forceinline__ void acc_v(f32x16& c, f16x8 a, f16x8 b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  }
+};
+template <> struct MfmaAsm<__bf16> {
+  static __device__ __forceinline__ void first_a(f32x16& c, bf16x8 a, bf16x8 b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "a"(b));
+  }
+  static __device__ __forceinline__ void acc_a(f32x16& c, bf16x8 a, bf16x8 b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+  }
+  static __device__ __forceinline__ void acc_v(f32x16& c, bf16x8 a, bf16x8 b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  }
+};
+// Global load of one fragment directly into accumulator registers (gfx90a+ VMEM may target AGPRs).
+template <typename F, typename P>
+__device__ __forceinline__ void agpr_load_frag(F& dst, const P* ptr) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(dst) : "v"(ptr) : "memory");
+}
+// LDS fragment read and counted wait, hidden from hipcc's waitcnt pass on purpose: it answers an asm consumer
+// with lgkmcnt(0), which drains the whole fragment ring.  LDS reads of one wave return in order, so
+// lgkmcnt(N) = "all but the N youngest reads have landed".
+template <typename F>
+__device__ __forceinline__ void lds_read_frag(F& dst, uint32_t addr, int off) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
+}
+// Diagnostic build only (VARIANT 2): shader-clock stamp, fenced so the segment it closes is complete.
+__device__ __forceinline__ uint64_t stamp() {
+  uint64_t t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+// 8-pass XDL result -> any non-MFMA reader needs 18 wait states the compiler cannot see inside asm.
+__device__ __forceinline__ void mfma_drain(f32x16& a0, f32x16& a1) {
+  asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a0), "+v"(a1));
+}
+
+// Wave-cooperative exact compaction of one lane's candidate buffer: keep the k largest keys
+// (sorted, descending) and return the k-th key.  All 64 lanes participate; buf/scratch/cnt are
+// wave-uniform.  Keys are unique (ids are unique), so ranks form a permutation.
+static __device__ __noinline__ uint64_t wave_compact(uint64_t* buf, uint64_t* scratch, int cnt, int k, int lane) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int e0 = 0; e0 < cnt; e0 += 64) {
+    const int e = e0 + lane;
+    const uint64_t mine = e < cnt ? buf[e] : ~0ull;
+    int rank = 0;
+    for (int j0 = 0; j0 < cnt; j0 += 64) {
+      const uint64_t v = (j0 + lane) < cnt ? buf[j0 + lane] : 0ull;
+      for (int t = 0; t < 64; ++t) {
+        const uint64_t o = __shfl(v, t, 64);
+        rank += o > mine ? 1 : 0;
+      }
+    }
+    if (e < cnt && rank < k) scratch[rank] = mine;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int e = lane; e < k; e += 64) buf[e] = scratch[e];
+  const uint64_t kth = scratch[k - 1];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  return kth;
+}
+
+// max without the canonicalising v_max(x,x) hipcc puts in front of fmaxf on MFMA results (NaN operands lose, as maxNum)
+__device__ __forceinline__ float max4(float a, float b, float c, float d) {
+  float t, r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(a), "v"(b), "v"(c));
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(d));
+  return r;
+}
+
+// Per-lane filter state: strict thresholds, candidate counts and buffer offsets of the lane's two queries.
+struct LaneState {
+  float thr0, thr1;
+  uint32_t cnt0, cnt1, off0, off1;
+};
+
+// Epilogue of one 32-row tile: a0/a1 hold the lane's 16 corpus rows (m = (i&3) + 8*(i>>2) + 4h) for its query of
+// block 0 / block 1.  DENSE: store every score.  Otherwise: strict-threshold filter, append survivors as order keys
+// to the lane's private buffers, compact exactly when a buffer is nearly full.
+template <bool DENSE>
+__device__ __forceinline__ void tile_epilogue(const ScanArgs& a, LaneState& st, const f32x16& a0, const f32x16& a1, uint32_t j,
+                                              uint32_t q0i, uint32_t q1i, int h, int lane, int wave) {
+    const uint32_t tile = a.tile_first + j * a.tile_stride;
+    if (DENSE) {
+      // column = j*32 + m, m = (i&3) + 8*(i>>2) + 4h
+      float* d0 = a.dense + (size_t)q0i * a.dense_ld + j * kTileRows + 4 * h;
+      float* d1 = a.dense + (size_t)q1i * a.dense_ld + j * kTileRows + 4 * h;
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+        *(f32x4*)(d0 + 8 * i4) = f32x4{a0[4 * i4], a0[4 * i4 + 1], a0[4 * i4 + 2], a0[4 * i4 + 3]};
+        *(f32x4*)(d1 + 8 * i4) = f32x4{a1[4 * i4], a1[4 * i4 + 1], a1[4 * i4 + 2], a1[4 * i4 + 3]};
+      }
+    } else {
+      // two-level test: maxima of the four 4-register groups (rows 8g+4h .. +3), then their maximum
+      float g0[4], g1[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        g0[g] = max4(a0[4 * g], a0[4 * g + 1], a0[4 * g + 2], a0[4 * g + 3]);
+        g1[g] = max4(a1[4 * g], a1[4 * g + 1], a1[4 * g + 2], a1[4 * g + 3]);
+      }
+      const float m0 = max4(g0[0], g0[1], g0[2], g0[3]);
+      const float m1 = max4(g1[0], g1[1], g1[2], g1[3]);
+      if (__builtin_amdgcn_ballot_w64(m0 > st.thr0 || m1 > st.thr1)) {
+        // rare: a typical hit is ONE lane with ONE score, so only the group that holds it is expanded
+        const uint32_t row0 = tile * kTileRows + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (__builtin_amdgcn_ballot_w64(g0[g] > st.thr0)) {
+#pragma unroll
+            for (int i = 4 * g; i < 4 * g + 4; ++i) {
+              const uint32_t id = row0 + (i & 3) + 8 * (i >> 2);
+              if (a0[i] > st.thr0 && id < a.n_rows) {
+                a.cand[(size_t)st.off0 + st.cnt0] = make_key(a0[i], id);
+                ++st.cnt0;
+              }
+            }
+          }
+          if (__builtin_amdgcn_ballot_w64(g1[g] > st.thr1)) {
+#pragma unroll
+            for (int i = 4 * g; i < 4 * g + 4; ++i) {
+              const uint32_t id = row0 + (i & 3) + 8 * (i >> 2);
+              if (a1[i] > st.thr1 && id < a.n_rows) {
+                a.cand[(size_t)st.off1 + st.cnt1] = make_key(a1[i], id);
+                ++st.cnt1;
+              }
+            }
+          }
+        }
+        // keep >= 16 free slots per buffer; compaction is exact and raises the lane threshold
+        const uint32_t lim = (uint32_t)a.cap - 16u;
+        if (__builtin_amdgcn_ballot_w64(st.cnt0 > lim || st.cnt1 > lim)) {
+          uint64_t* scratch = a.scratch + (size_t)(blockIdx.x * 4 + wave) * a.cap;
+#pragma unroll 1
+          for (int b = 0; b < 2; ++b) {
+            uint64_t mask = __builtin_amdgcn_ballot_w64((b ? st.cnt1 : st.cnt0) > lim);
+            while (mask) {
+              const int L = __builtin_ctzll(mask);
+              mask &= mask - 1;
+              const uint32_t off = __shfl(b ? st.off1 : st.off0, L, 64);
+              const int cnt = (int)__shfl(b ? st.cnt1 : st.cnt0, L, 64);
+              const uint64_t kth = wave_compact(a.cand + (size_t)__builtin_amdgcn_readfirstlane(off), scratch,
+                                                __builtin_amdgcn_readfirstlane(cnt), a.k, lane);
+              if (lane == L) {
+                if (b) { st.cnt1 = a.k; st.thr1 = key_score(kth); }
+                else   { st.cnt0 = a.k; st.thr0 = key_score(kth); }
+              }
+            }
+          }
+        }
+      }
+    }
+}
+
+// 16x16x32 MFMA shape.  Same design, registers and LDS image as flat_scan_kernel; the chip holds a higher clock on
+// this shape under the combined HBM + MFMA load (measured: -6.7 % time at equal flops and operands), which is what
+// bounds the kernel.  Per wave: 4 query blocks of 16 (B operand) x 2 row blocks of 16 (A operand); D fragment:
+// column = lane&15 -> query, rows 4*(lane>>4) + reg.  A lane therefore owns 4 queries x 8 rows per tile, and the
+// candidate buffers are per (workgroup, query, lane quarter): 4 per workgroup and query.
+template <typename T> struct Mfma16Asm;
+#define RR_MFMA16(NAME, MNEMONIC, FRAG)                                                                        \
+  template <> struct Mfma16Asm<NAME> {                                                                          \
+    static __device__ __forceinline__ void first_a(f32x4& c, FRAG a, FRAG b) {                                  \
+      asm volatile(MNEMONIC " %0, %1, %2, 0" : "=v"(c) : "v"(a), "a"(b));                                      \
+    }                                                                                                           \
+    static __device__ __forceinline__ void first_v(f32x4& c, FRAG a, FRAG b) {                                  \
+      asm volatile(MNEMONIC " %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));                                      \
+    }                                                                                                           \
+    static __device__ __forceinline__ void acc_a(f32x4& c, FRAG a, FRAG b) {                                    \
+      asm volatile(MNEMONIC " %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));                                     \
+    }                                                                                                           \
+    static __device__ __forceinline__ void acc_v(f32x4& c, FRAG a, FRAG b) {                                    \
+      asm volatile(MNEMONIC " %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));                                     \
+    }                                                                                                           \
+  };
+RR_MFMA16(_Float16, "v_mfma_f32_16x16x32_f16", f16x8)
+RR_MFMA16(__bf16, "v_mfma_f32_16x16x32_bf16", bf16x8)
+RR_MFMA16(I8Pair, "v_mfma_i32_16x16x64_i8", s16x8)  // i32 accumulators, converted to f32 (exact: |dot| < 2^24 for 2*D <= 1536) before the epilogue
+#undef RR_MFMA16
+
+constexpr int kTicketBatch = 4;  // tiles per dynamic ticket
+
+// LDS ring depth of flat_scan16_kernel.  What must stay in flight per CU is BYTES (~96 KB against the loaded HBM latency:
+// 256 CUs x 96 KB / 2.5 us ~ 9.8 TB/s), so narrow rows need more slots; measured with 3 slots: d=384 streamed 3.8 TB/s.
+// (INFL-1)*(KG+1) <= 63 (vmcnt range) holds for every entry.
+__host__ __device__ constexpr int scan16_slots(int D) { return D >= 640 ? 3 : D == 512 ? 4 : D == 384 ? 6 : D == 256 ? 7 : 13; }
+
+struct LaneState4 {
+  float thr[4];
+  uint32_t cnt[4], off[4];
+};
+
+__device__ __forceinline__ float max4v(const f32x4& v) { return max4(v[0], v[1], v[2], v[3]); }
+
+template <bool DENSE, int NQB, int QPW = 64>
+__device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& st, f32x4 (&acc)[2][4], uint32_t j, int lane, int wave) {
+  const int col = lane & 15, g = lane >> 4;
+  const uint32_t tile = a.tile_first + j * a.tile_stride;
+  if (DENSE) {
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+      float* d = a.dense + (size_t)(wave * QPW + qb * 16 + col) * a.dense_ld + j * kTileRows + 4 * g;
+      *(f32x4*)d = acc[0][qb];
+      *(f32x4*)(d + 16) = acc[1][qb];
+    }
+    return;
+  }
+  float gm[2][4];
+  bool hit = false;
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) {
+    gm[0][qb] = max4v(acc[0][qb]);
+    gm[1][qb] = max4v(acc[1][qb]);
+    hit = hit || (gm[0][qb] > st.thr[qb]) || (gm[1][qb] > st.thr[qb]);
+  }
+  if (!__builtin_amdgcn_ballot_w64(hit)) return;
+  // rare: typically ONE lane with ONE score; only the 4-row group that holds it is expanded
+  const uint32_t row0 = tile * kTileRows + 4 * g;
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      if (__builtin_amdgcn_ballot_w64(gm[rb][qb] > st.thr[qb])) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t id = row0 + rb * 16 + i;
+          if (acc[rb][qb][i] > st.thr[qb] && id < a.n_rows) {
+            a.cand[(size_t)st.off[qb] + st.cnt[qb]] = make_key(acc[rb][qb][i], id);
+            ++st.cnt[qb];
+          }
+        }
+      }
+    }
+  }
+  const uint32_t lim = (uint32_t)a.cap - 16u;
+  bool full = false;
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) full = full || st.cnt[qb] > lim;
+  if (__builtin_amdgcn_ballot_w64(full)) {
+    uint64_t* scratch = a.scratch + (size_t)(blockIdx.x * (256 / QPW) + wave) * a.cap;
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+      uint64_t mask = __builtin_amdgcn_ballot_w64(st.cnt[qb] > lim);
+      while (mask) {
+        const int L = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const uint32_t off = __shfl(st.off[qb], L, 64);
+        const int cnt = (int)__shfl(st.cnt[qb], L, 64);
+        const uint64_t kth = wave_compact(a.cand + (size_t)__builtin_amdgcn_readfirstlane(off), scratch,
+                                          __builtin_amdgcn_readfirstlane(cnt), a.k, lane);
+        if (lane == L) { st.cnt[qb] = a.k; st.thr[qb] = key_score(kth); }
+      }
+    }
+  }
+}
+
+template <int... Is, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }  // body sees a constexpr index
+
+// Corpora beyond the 256 MiB Infinity Cache are streamed with non-temporal LDS-DMA (read once per batch: -1.7 % at
+// B=256, -11 % for single-query searches); smaller ones keep the default policy so back-to-back searches stay on die.
+constexpr size_t kNtThresholdBytes = 256ull << 20;
+
+// flat_scan_dev.hip (only in builds with -DRR_DEV_VARIANTS): the development kernels behind RR_SCAN_VARIANT / RR_GENERIC_TALL
+bool dev_scan_handles(const ScanArgs& a, int D, int variant, int tall);
+int dev_scan_bufs_per_wg(int D, int variant, int tall);
+hipError_t launch_dev_scan(const ScanArgs& a, int dtype, int D, bool dense, int grid, hipStream_t st, int variant, int tall);
+
+}  // namespace rr

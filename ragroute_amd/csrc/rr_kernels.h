@@ -26,7 +26,7 @@ struct ScanArgs {
 // flat_scan.hip
 hipError_t launch_flat_scan(const ScanArgs& a, int dtype, int D, bool dense, int grid, hipStream_t st);
 int scan_padded_dim(int d);
-int scan_bufs_per_wg(int D);
+int scan_bufs_per_wg(int D, bool l2);
 int scan_queries_per_launch(int D, int nq);  // nq = queries of the whole call
 
 // select.hip

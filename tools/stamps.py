@@ -1,4 +1,4 @@
-"""Diagnostic (RR_SCAN_VARIANT=2): share of the scan loop's cycles per segment, from in-kernel s_memtime stamps."""
+"""Diagnostic (library built with RR_DEV_VARIANTS=1, RR_SCAN_VARIANT=2): share of the scan loop's cycles per segment, from in-kernel s_memtime stamps."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["RR_SCAN_VARIANT"] = "2"
