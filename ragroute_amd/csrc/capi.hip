@@ -53,14 +53,13 @@ hipError_t profiled_scan(const rr::ScanArgs& a, int dtype, int D, bool dense, in
 }
 
 // Schedule knobs (defaults from rr_common.h; RR_SAMPLE_ROWS / RR_CHUNK_GROWTH override them for tuning runs)
-int g_sample_rows = rr::kSampleRows, g_chunk_growth = rr::kChunkGrowth, g_dynamic_tiles = 0;  // RR_DYNAMIC_TILES=1: ticketed tiles (no gain: see DESIGN.md)
+int g_sample_rows = rr::kSampleRows, g_chunk_growth = rr::kChunkGrowth;
 void read_schedule_env() {
   static const bool once = [] {
     if (const char* v = getenv("RR_SAMPLE_ROWS")) {
       int r = atoi(v) / rr::kTileRows * rr::kTileRows;
       if (r >= 1024 && r <= rr::kSampleRows) g_sample_rows = r;
     }
-    if (const char* v = getenv("RR_DYNAMIC_TILES")) g_dynamic_tiles = atoi(v);
     if (const char* v = getenv("RR_CHUNK_GROWTH")) {
       int g = atoi(v);
       if (g >= 2 && g <= 1024) g_chunk_growth = g;
@@ -206,12 +205,9 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
       RR_CHECK(launch_dense_select(s, true, st), "rr_flat_search/bootstrap_select");
       // chunks [0,e1), [e1,e2), ... with e growing 8x: ~7k survivors per query and chunk
       uint64_t begin = 0, end = (uint64_t)n_sample_tiles * g_chunk_growth;  // in tiles
-      int launch_no = 0;
       while (begin < total_tiles) {
         if (end > total_tiles) end = total_tiles;
         a.tile_first = (uint32_t)begin; a.tile_stride = 1; a.n_tiles = (uint32_t)(end - begin);
-        a.tile_counter = (g_dynamic_tiles && launch_no < 16) ? w.tile_counters + 16 * launch_no : nullptr;
-        ++launch_no;
         a.timeline = getenv("RR_SCAN_TIMELINE") ? (uint64_t*)w.dense : nullptr;  // the dense buffer is idle during chunk scans
         RR_CHECK(profiled_scan(a, dtype, dim, false, grid, st), "rr_flat_search/scan");
         RR_CHECK(launch_compact(s, st), "rr_flat_search/compact");

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   constexpr int KG = D / 64;         // 64-wide k groups (DMA pieces)
   constexpr int NF = 2 * KS2;        // corpus fragments per tile (2 row blocks per slice)
   constexpr int NQ = 4 * KS2;        // resident query fragments per wave
-  constexpr int NAQ = NQ < 62 ? NQ : 62;  // ... of which live in AGPRs (4*62 = 248)
+  constexpr int NAQ = NQ < 64 ? NQ : 64;  // ... of which live in AGPRs (all 256)
   constexpr int TILE_BYTES = kTileRows * D * 2;
   constexpr int NS = scan16_slots(D);  // LDS ring slots; NS - 1 tiles are in flight while one is computed
   constexpr int INFL = NS - 1;
@@ -97,33 +97,12 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.half_sqnorm + row),
                                      (__attribute__((address_space(3))) void*)(smem + NS * TILE_BYTES + slot_ * 256), 4, 0, 0);
   };
-  const bool norm_wave = L2 && wave == 1;  // not the ticket wave (wave 0)
-
-  // Tile schedule.  Static: ordinals blockIdx, +grid, +2 grid, ...  Dynamic (a.tile_counter): the first two ordinals are
-  // static, later ones come in batches of kTicketBatch consecutive ordinals 2*grid + atomicAdd(counter, kTicketBatch)
-  // (one dequeue per tile from 256 workgroups would exceed what a single counter word sustains, ~88 per us): XCDs run at different speeds (measured 7.5 % apart
-  // under load) and a static split makes every launch wait for the slowest one.  Wave 0 requests the ticket ONE tile
-  // ahead with an asm returning atomic that sits in the in-order vmcnt queue before that tile's DMA pieces, so the
-  // tile's own vmcnt wait covers it; lane 0 posts it to LDS before the barrier, every wave reads it after.
+  const bool norm_wave = L2 && wave == 1;
+  // Tile schedule: static round-robin, ordinals blockIdx, +grid, +2 grid, ...  (Ticketed dynamic tiles - XCDs run up to 7.5 %
+  // apart under load - levelled the finish times without shortening the launch and were removed; see DESIGN.md.)
   const uint32_t stride = gridDim.x;
   const uint32_t n_tiles = a.n_tiles;
-  const bool dyn = NS == 3 && a.tile_counter != nullptr;  // (tickets are wired for the 3-slot ring only)
-  uint32_t* ticket_lds = (uint32_t*)(smem + NS * TILE_BYTES + NS * 256);  // 2 alternating words
-  // The atomic returns asynchronously, so its destination must not be a compiler-visible value (hipcc copies such a
-  // register right after the asm statement, before the data lands - seen in the ISA).  It returns into the hard-wired
-  // accumulator register a255, claimed through clobbers, and is read inside the same asm statement as the covering vmcnt.
-  // A returning atomic is not guaranteed to complete in order with the LDS-DMA loads of the vmcnt queue, so no counted
-  // wait can cover it: a255 is pre-loaded with a sentinel and polled at consume time until the return has landed
-  // (normally zero spins: the request is a whole tile old).
-  const uint32_t one = kTicketBatch, sentinel = 0xFFFFFFFFu;  // a ticket = kTicketBatch consecutive tile ordinals
-  auto request_ticket = [&]() {
-    if (dyn && wave == 0 && lane == 0)  // ONE lane: every active lane would add to the counter
-      // VMEM atomics share one acc bit for data and destination: the addend lives in a254
-      asm volatile("v_accvgpr_write_b32 a254, %1\n\tv_accvgpr_write_b32 a255, %2\n\ts_nop 1\n\tglobal_atomic_add a255, %0, a254, off sc0"
-                   ::"v"(a.tile_counter), "v"(one), "v"(sentinel) : "memory", "a254", "a255");
-  };
-  uint32_t j = blockIdx.x, j1 = blockIdx.x + stride;
-  request_ticket();
+  uint32_t j = blockIdx.x;
   if (j < n_tiles) {
 #pragma unroll
     for (int t = 0; t < INFL; ++t) {
@@ -163,42 +142,25 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
     st.off[qb] = (qi * nbuf + blockIdx.x * 4 + g) * (uint32_t)a.cap;
   }
 
-  int slot = 0, par = 0, sub = kTicketBatch;
-  uint32_t base = 0, dbg_iter = 0;
+  // The initial thresholds are global loads: make them land here (the queue was drained for the query loads anyway).  Left to
+  // hipcc, their first use inside the loop gets an s_waitcnt vmcnt(0) that then drains the DMA ring on EVERY tile.
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(st.thr[0]), "+v"(st.thr[1]), "+v"(st.thr[2]), "+v"(st.thr[3]));
+  int slot = 0;
+  uint32_t dbg_iter = 0;
   while (j < n_tiles) {
-    // queue (oldest first): [norms t] DMA t  ticket [norms t+1] DMA t+1 ... -> all but the pieces of the INFL-1 younger tiles
+    // queue (oldest first): [norms t] DMA t  [norms t+1] DMA t+1 ... -> all but the pieces of the INFL-1 younger tiles
     // (KG each, +1 on the norm wave) are done
     if (norm_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((INFL - 1) * (KG + 1)) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((INFL - 1) * KG) : "memory");
-    const bool fetch = dyn && sub == kTicketBatch;  // workgroup-uniform: a new batch of kTicketBatch consecutive tiles starts
-    if (fetch && wave == 0) {
-      uint32_t ticket;
-      do {
-        uint32_t tk;
-        asm volatile("v_accvgpr_read_b32 %0, a255" : "=v"(tk)::"a255");
-        ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
-      } while (ticket == sentinel);
-      if (lane == 0) ticket_lds[par] = 2 * stride + ticket;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // a raw s_barrier does not wait for the LDS store
-    }
     if (a.timeline && threadIdx.x == 0) {  // diagnostics only: tile sequence, and the time the first tile became ready
       if (dbg_iter == 0) a.timeline[3 * gridDim.x + 64 * gridDim.x + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-      a.timeline[3 * gridDim.x + blockIdx.x * 64 + (dbg_iter++ & 63)] = j;
+      a.timeline[3 * gridDim.x + blockIdx.x * 64 + (dbg_iter & 63)] = j;
     }
+    if (a.timeline) ++dbg_iter;
     __builtin_amdgcn_s_barrier();
     int nslot = slot + INFL;
     if (nslot >= NS) nslot -= NS;
     uint32_t j2 = j + INFL * stride;
-    if (dyn) {
-      if (fetch) {
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket_lds[par]);
-        par ^= 1;
-        sub = 0;
-        request_ticket();  // the next batch: kTicketBatch tiles of lead time, issued before this tile's norms / DMA pieces
-      }
-      j2 = base + sub;
-      ++sub;
-    }
     const char* gn = tile_src(j2);
     if (norm_wave) issue_norms(j2, nslot);
     auto compute = [&](auto tag) {
@@ -256,8 +218,8 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
             for (int i = 0; i < 4; ++i) acc[rb][qb][i] = (float)__float_as_int(acc[rb][qb][i]);
       }
       if (L2) {
-        const f32x4 h0 = *(const f32x4*)(smem + NS * TILE_BYTES + slot * 256 + (4 * g) * 4);
-        const f32x4 h1 = *(const f32x4*)(smem + NS * TILE_BYTES + slot * 256 + (16 + 4 * g) * 4);
+        const f32x4 h0 = lds_load_f32x4((uint32_t)(NS * TILE_BYTES + slot * 256 + (4 * g) * 4));
+        const f32x4 h1 = lds_load_f32x4((uint32_t)(NS * TILE_BYTES + slot * 256 + (16 + 4 * g) * 4));
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb) {
           acc[0][qb] -= h0;
@@ -276,10 +238,9 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
     }
     slot = slot + 1;
     if (slot >= NS) slot = 0;
-    j = dyn ? j1 : j + stride;
-    j1 = j2;
+    j += stride;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory", "a255");  // no LDS-DMA (or ticket) may outlive the workgroup
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
   if (!DENSE) {
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) a.cand_cnt[(wave * 64 + qb * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
@@ -800,7 +761,7 @@ int scan_bufs_per_wg(int D, bool l2) {
 
 template <typename T, int D, bool DENSE, bool NT = false, bool L2 = false>
 static hipError_t launch_scan16(const ScanArgs& a, int grid, hipStream_t st) {
-  const size_t lds = scan16_slots(D) * ((size_t)kTileRows * D * 2 + 256) + 16;  // ring + L2 norm slots + ticket words
+  const size_t lds = scan16_slots(D) * ((size_t)kTileRows * D * 2 + 256);  // ring + L2 norm slots
   hipError_t e = hipFuncSetAttribute((const void*)flat_scan16_kernel<T, D, DENSE, NT, L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((flat_scan16_kernel<T, D, DENSE, NT, L2>), dim3(grid), dim3(256), lds, st, a);

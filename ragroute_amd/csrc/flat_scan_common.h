@@ -230,12 +230,23 @@ RR_MFMA16(__bf16, "v_mfma_f32_16x16x32_bf16", bf16x8)
 RR_MFMA16(I8Pair, "v_mfma_i32_16x16x64_i8", s16x8)  // i32 accumulators, converted to f32 (exact: |dot| < 2^24 for 2*D <= 1536) before the epilogue
 #undef RR_MFMA16
 
-constexpr int kTicketBatch = 4;  // tiles per dynamic ticket
-
 // LDS ring depth of flat_scan16_kernel.  What must stay in flight per CU is BYTES (~96 KB against the loaded HBM latency:
 // 256 CUs x 96 KB / 2.5 us ~ 9.8 TB/s), so narrow rows need more slots; measured with 3 slots: d=384 streamed 3.8 TB/s.
 // (INFL-1)*(KG+1) <= 63 (vmcnt range) holds for every entry.
 __host__ __device__ constexpr int scan16_slots(int D) { return D >= 640 ? 3 : D == 512 ? 4 : D == 384 ? 6 : D == 256 ? 7 : 13; }
+
+// LDS reads hidden from hipcc: next to LDS-DMA it answers every LDS load it can see with s_waitcnt vmcnt(0), which drains
+// the DMA ring of the scan kernels.  Each statement waits for its own data (the fragment ring is empty wherever these are used).
+__device__ __forceinline__ float lds_load_f32(uint32_t byte_addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(byte_addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ f32x4 lds_load_f32x4(uint32_t byte_addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(byte_addr) : "memory");
+  return v;
+}
 
 struct LaneState4 {
   float thr[4];
