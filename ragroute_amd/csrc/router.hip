@@ -34,16 +34,26 @@ __global__ __launch_bounds__(1024) void router_mlp_kernel(rr_router_weights w, c
   const int m = blockIdx.y;
   const int q0 = blockIdx.x * 4;
 
+  // Embeddings are zero padded to d_max (router.py:245-249): FeB4RAG pads 768- and 1024-wide models to 4096.  Zeros add
+  // nothing to fc1, so the k loop stops at the last non-zero input of the workgroup's 4 queries (bit-identical sums).
+  __shared__ int k_end_s;
+  if (tid == 0) k_end_s = 0;
+  __syncthreads();
+  int last = 0;
   for (int i = tid; i < 4 * dmax; i += 1024) {
     const int t = i / dmax, k = i - t * dmax;
     const int q = q0 + t;
-    xs[i] = q < nq ? xq[((size_t)q * w.n_models + m) * dmax + k] : 0.f;
+    const float v = q < nq ? xq[((size_t)q * w.n_models + m) * dmax + k] : 0.f;
+    xs[i] = v;
+    if (v != 0.f) last = k + 1;   // (NaN != 0 is true: a NaN input still reaches fc1)
   }
+  if (last) atomicMax(&k_end_s, last);
   __syncthreads();
   {
     const int ks = tid >> 8, j = tid & 255;
-    const int kq = (dmax + 3) / 4;
-    const int k0 = ks * kq, k1 = min(dmax, k0 + kq);
+    const int kend = k_end_s;
+    const int kq = (kend + 3) / 4;
+    const int k0 = ks * kq, k1 = min(kend, k0 + kq);
     float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
     const float* wp = w.w1q + j;
 #pragma unroll 8
