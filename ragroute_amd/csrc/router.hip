@@ -20,16 +20,14 @@ __device__ __forceinline__ float wsum(float v) {
 
 // 1024 threads = 16 waves.  Phase 1: thread (ks, j) accumulates fc1 output j over the k-quarter ks for the 4 queries
 // of the workgroup (4x the loads in flight of a 256-thread version; the loop is latency-bound on L2), partial sums
-// meet in LDS.  Phase 2: wave (t, part) = query t, input quarter `part` of fc2; quarter sums meet in LDS and wave
-// (t, 0) finishes LayerNorm128, fc3, sigmoid, threshold.
+// meet in LDS.  Phase 2: one wave per (query, source) row, see below.
 __global__ __launch_bounds__(1024) void router_mlp_kernel(rr_router_weights w, const float* __restrict__ xq, int nq,
                                                           float* __restrict__ logits, uint8_t* __restrict__ mask) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int dmax = w.d_max;
   float* xs = lds;                 // [4][dmax]
   float* up = lds + 4 * dmax;      // [4 ks][4 t][256] fc1 partials
-  float* hs = up + 16 * 256;       // [4 t][256] h1
-  float* fp = hs + 4 * 256;        // [4 t][4 part][128] fc2 partials
+  float* hs = up + 16 * 256;       // [16 waves][256] h1 of the (query, source) row a wave is working on
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = blockIdx.y;
   const int q0 = blockIdx.x * 4;
@@ -69,70 +67,65 @@ __global__ __launch_bounds__(1024) void router_mlp_kernel(rr_router_weights w, c
   }
   __syncthreads();
 
-  const int t = wave & 3, part = wave >> 2;
+  // Phase 2: wave (t, slot) owns query t and every 4th source of this model; LayerNorm256, fc2 (each lane two of the 128
+  // outputs over all 256 inputs), LayerNorm128, fc3 run inside the wave - no workgroup barrier, 16 (query, source) rows in flight.
+  const int t = wave & 3, slot = wave >> 2;
   const int q = q0 + t;
   const bool active = q < nq;  // wave-uniform
+  float* hw = hs + wave * 256;
+  int ordinal = 0;
   for (int c = 0; c < w.n_sources; ++c) {
     if (w.model_of_source[c] != m) continue;  // workgroup-uniform
-    if (part == 0 && active) {
-      float v[4], s = 0.f;
+    if ((ordinal++ & 3) != slot || !active) continue;
+    float v[4], s = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int j = lane + 64 * i;
-        v[i] = ((up[t * 256 + j] + up[1024 + t * 256 + j]) + (up[2048 + t * 256 + j] + up[3072 + t * 256 + j])) + w.c1[c * 256 + j];
-        s += v[i];
-      }
-      const float mean = wsum(s) * (1.f / 256.f);
-      float sq = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { v[i] -= mean; sq += v[i] * v[i]; }
-      const float rstd = 1.0f / sqrtf(wsum(sq) * (1.f / 256.f) + w.ln_eps);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int j = lane + 64 * i;
-        hs[t * 256 + j] = fmaxf(v[i] * rstd * w.ln1_g[j] + w.ln1_b[j], 0.f);
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int j = lane + 64 * i;
+      v[i] = ((up[t * 256 + j] + up[1024 + t * 256 + j]) + (up[2048 + t * 256 + j] + up[3072 + t * 256 + j])) + w.c1[c * 256 + j];
+      s += v[i];
     }
-    __syncthreads();
-    if (active) {
-      float a0 = 0.f, a1 = 0.f;
-      const float* ht = hs + t * 256 + part * 64;
-      const float* w2 = w.w2 + (size_t)(part * 64) * 128 + lane;
+    const float mean = wsum(s) * (1.f / 256.f);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] -= mean; sq += v[i] * v[i]; }
+    const float rstd = 1.0f / sqrtf(wsum(sq) * (1.f / 256.f) + w.ln_eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = lane + 64 * i;
+      hw[j] = fmaxf(v[i] * rstd * w.ln1_g[j] + w.ln1_b[j], 0.f);
+    }
+    __builtin_amdgcn_wave_barrier();  // hw is written and read by this wave only; LDS operations of one wave complete in order
+    float a0 = 0.f, a1 = 0.f, c0 = 0.f, c1v = 0.f;
+    const float* w2 = w.w2 + lane;
 #pragma unroll 16
-      for (int i = 0; i < 64; ++i) {
-        const float hv = ht[i];
-        a0 = fmaf(hv, w2[i * 128], a0);
-        a1 = fmaf(hv, w2[i * 128 + 64], a1);
-      }
-      fp[(t * 4 + part) * 128 + lane] = a0;
-      fp[(t * 4 + part) * 128 + lane + 64] = a1;
+    for (int i = 0; i < 256; i += 2) {   // two independent chains per output; 64 loads in flight per lane (the loop is L2-latency bound)
+      const float h0 = hw[i], h1 = hw[i + 1];
+      a0 = fmaf(h0, w2[i * 128], a0);
+      a1 = fmaf(h0, w2[i * 128 + 64], a1);
+      c0 = fmaf(h1, w2[(i + 1) * 128], c0);
+      c1v = fmaf(h1, w2[(i + 1) * 128 + 64], c1v);
     }
-    __syncthreads();
-    if (part == 0 && active) {
-      const float* f = fp + t * 512;
-      float a0 = ((f[lane] + f[128 + lane]) + (f[256 + lane] + f[384 + lane])) + w.b2[lane];
-      float a1 = ((f[lane + 64] + f[128 + lane + 64]) + (f[256 + lane + 64] + f[384 + lane + 64])) + w.b2[lane + 64];
-      const float mean2 = wsum(a0 + a1) * (1.f / 128.f);
-      a0 -= mean2; a1 -= mean2;
-      const float rstd2 = 1.0f / sqrtf(wsum(a0 * a0 + a1 * a1) * (1.f / 128.f) + w.ln_eps);
-      const float h0 = fmaxf(a0 * rstd2 * w.ln2_g[lane] + w.ln2_b[lane], 0.f);
-      const float h1 = fmaxf(a1 * rstd2 * w.ln2_g[lane + 64] + w.ln2_b[lane + 64], 0.f);
-      const float logit = wsum(h0 * w.w3[lane] + h1 * w.w3[lane + 64]) + w.b3;
-      if (lane == 0) {
-        logits[(size_t)q * w.n_sources + c] = logit;
-        const float p = 1.0f / (1.0f + expf(-logit));
-        mask[(size_t)q * w.n_sources + c] = p > w.prob_threshold ? 1 : 0;
-      }
+    a0 = (a0 + c0) + w.b2[lane];
+    a1 = (a1 + c1v) + w.b2[lane + 64];
+    const float mean2 = wsum(a0 + a1) * (1.f / 128.f);
+    a0 -= mean2; a1 -= mean2;
+    const float rstd2 = 1.0f / sqrtf(wsum(a0 * a0 + a1 * a1) * (1.f / 128.f) + w.ln_eps);
+    const float h0 = fmaxf(a0 * rstd2 * w.ln2_g[lane] + w.ln2_b[lane], 0.f);
+    const float h1 = fmaxf(a1 * rstd2 * w.ln2_g[lane + 64] + w.ln2_b[lane + 64], 0.f);
+    const float logit = wsum(h0 * w.w3[lane] + h1 * w.w3[lane + 64]) + w.b3;
+    if (lane == 0) {
+      logits[(size_t)q * w.n_sources + c] = logit;
+      const float p = 1.0f / (1.0f + expf(-logit));
+      mask[(size_t)q * w.n_sources + c] = p > w.prob_threshold ? 1 : 0;
     }
-    // hs / fp are rewritten only after the next iteration's first barrier... guard the WAR on fp explicitly
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();  // the next source of this wave rewrites hw
   }
 }
 
 hipError_t launch_router_mlp(const rr_router_weights* w, const float* xq, int nq, float* logits, uint8_t* mask,
                              hipStream_t st) {
   if (nq == 0) return hipSuccess;
-  const size_t lds = (size_t)(4 * w->d_max + 16 * 256 + 4 * 256 + 16 * 128) * sizeof(float);
+  const size_t lds = (size_t)(4 * w->d_max + 16 * 256 + 16 * 256) * sizeof(float);
   hipError_t e = hipFuncSetAttribute((const void*)router_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(router_mlp_kernel, dim3((nq + 3) / 4, w->n_models), dim3(1024), lds, st, *w, xq, nq, logits, mask);
