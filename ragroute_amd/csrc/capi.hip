@@ -74,7 +74,6 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct Workspace {
   float* thr;
   uint32_t* list_cnt;
-  uint32_t* tile_counters;
   uint64_t* list;
   uint32_t* cand_cnt;
   uint64_t* scratch;
@@ -91,7 +90,6 @@ Workspace carve(char* base, int k, int grid) {
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return base ? base + o : (char*)nullptr; };
   w.thr = (float*)take(kQueriesPerBlock * sizeof(float));
   w.list_cnt = (uint32_t*)take(kQueriesPerBlock * sizeof(uint32_t));
-  w.tile_counters = (uint32_t*)take(16 * 64);  // one 64-byte line per scan launch of a search
   w.list = (uint64_t*)take((size_t)kQueriesPerBlock * kMaxK * sizeof(uint64_t));
   w.cand_cnt = (uint32_t*)take((size_t)kQueriesPerBlock * grid * 4 * sizeof(uint32_t));
   w.scratch = (uint64_t*)take((size_t)grid * 8 * cap * sizeof(uint64_t));  // up to 2 workgroups per CU x 4 waves
@@ -180,7 +178,7 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
 
     SelectArgs s;
     memset(&s, 0, sizeof(s));
-    s.thr = w.thr; s.list = w.list; s.list_cnt = w.list_cnt; s.tile_counters = w.tile_counters; s.cand = w.cand; s.cand_cnt = w.cand_cnt;
+    s.thr = w.thr; s.list = w.list; s.list_cnt = w.list_cnt; s.cand = w.cand; s.cand_cnt = w.cand_cnt;
     s.dense = w.dense; s.dense_ld = kSampleRows; s.n_rows = (uint32_t)n_rows; s.nq = (uint32_t)nqb;
     s.nbuf = (uint32_t)grid * (uint32_t)(dtype == kDtypeI8 ? 4 : scan_bufs_per_wg(dim, half_sqnorm != nullptr)); s.list_ld = kMaxK; s.cap = cap; s.k = k;
     ScanArgs a;

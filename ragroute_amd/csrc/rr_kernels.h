@@ -15,7 +15,6 @@ struct ScanArgs {
   uint64_t* scratch;    // [grid*4][cap] per-wave compaction scratch
   float* dense;         // [256][dense_ld] scores (dense mode)
   const float* half_sqnorm;  // L2 metric: |x|^2/2 per row, else nullptr
-  uint32_t* tile_counter;    // dynamic tile tickets (zeroed before the launch), nullptr = static round-robin
   uint64_t* timeline;        // diagnostics (RR_SCAN_TIMELINE): per-workgroup start / end s_memrealtime, else nullptr
   uint32_t n_rows, nq;
   uint32_t tile_first, tile_stride, n_tiles;  // tile(j) = tile_first + j*tile_stride, j < n_tiles
@@ -34,7 +33,6 @@ struct SelectArgs {
   float* thr;           // [256]
   uint64_t* list;       // [256][list_ld] running top-k keys, sorted descending
   uint32_t* list_cnt;   // [256]
-  uint32_t* tile_counters;  // [16] ticket counters of the scan launches, zeroed by init_state
   const uint64_t* cand; const uint32_t* cand_cnt;  // as ScanArgs
   const float* dense; uint32_t dense_ld, dense_cols;
   uint32_t tile_first, tile_stride;  // dense column c <-> row (tile_first + (c/32)*tile_stride)*32 + c%32

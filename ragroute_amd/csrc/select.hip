@@ -25,7 +25,6 @@ __global__ void init_state_kernel(SelectArgs a) {
   if (q < kQueriesPerBlock) {
     a.list_cnt[q] = 0;
     a.thr[q] = q < a.nq ? -__builtin_inff() : __builtin_inff();
-    a.tile_counters[q] = 0;  // 256 words: one 64-byte line per scan launch
   }
 }
 
