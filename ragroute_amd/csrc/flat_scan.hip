@@ -482,15 +482,17 @@ template <int N, typename F>
 __device__ __forceinline__ void vm_wait_tied8(F& r0, F& r1, F& r2, F& r3, F& r4, F& r5, F& r6, F& r7) {
   asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "n"(N) : "memory");
 }
+// DENSE launches (bootstrap sample, corpora <= 8192 rows) cover at most 256 tiles: with 8-tile groups only 32 workgroups would
+// have work and each would still walk the whole K loop (112 us at d = 4096), so they use one tile per group.
 template <typename T, bool DENSE, bool L2 = false>
 __global__ __launch_bounds__(256, 1) void flat_scan_wide_kernel(const ScanArgs a, const int D) {
   typedef typename Mfma<T>::frag frag;
-  constexpr int NT = 8;                    // 32-row tiles per group
+  constexpr int NT = DENSE ? 1 : 8;        // 32-row tiles per group
   constexpr int STEP_BYTES = NT * 4096;    // one K step of one group in LDS
   constexpr int NS = 3;
   constexpr int LEAD = NS - 1;             // K steps the DMA stream runs ahead
   constexpr int NF = 4 * NT;               // A fragments per K step: (tile, s2, rb)
-  constexpr int NB = 8;
+  constexpr int NB = NF < 8 ? NF : 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -708,7 +710,7 @@ static hipError_t launch_scan_half_resident(const ScanArgs& a, int D, bool dense
 template <typename T>
 static hipError_t launch_scan_wide(const ScanArgs& a, int D, bool dense, int grid, hipStream_t st) {
   if (D % 128 != 0) return hipErrorInvalidValue;
-  const size_t lds = 3 * 8 * 4096;
+  const size_t lds = 3 * (dense ? 1 : 8) * 4096;
   hipError_t e;
 #define RR_LAUNCH_W(DENSE_, L2_)                                                                                             \
   {                                                                                                                         \
