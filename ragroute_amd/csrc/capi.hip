@@ -103,7 +103,7 @@ Workspace carve(char* base, int k, int grid) {
 
 extern "C" {
 
-int rr_version(void) { return 100; }
+int rr_version(void) { return 200; }  // 0.2.0: screened search, wide rows, L2 for every dimension
 const char* rr_last_error(void) { return g_err; }
 int rr_device_cus(void) {
   int v = device_cus();
