@@ -274,3 +274,25 @@ def test_committed_fixture(gpu, case, dtype):
         assert np.array_equal(D.astype(np.float64), G["int_D"])
     else:
         assert np.allclose(D, G[case + "_D"], atol=1e-3, rtol=0)
+
+
+@pytest.mark.parametrize("d,nq", [(1024, 200), (1024, 3), (2048, 130), (4096, 17)])
+def test_wide_rows_adversarial(gpu, d, nq):
+    """The wide-row kernel (and the half-resident one for small batches at 1024) under the same adversarial inputs as the
+    d = 768 kernel: ascending scores (every tile beats every threshold, buffers overflow), all-equal scores, NaN rows,
+    a partial last query block, k = 100 - bit-exact against the oracle on integer data."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(d + nq)
+    n, k = 40_000, 100
+    xb = int_data(rng, n, d, -1, 2)
+    xb[:, 0] = np.arange(n) // 40                      # <= 999, exact in fp16
+    bad = rng.choice(n, size=10, replace=False)
+    xb[bad, 5] = np.nan
+    xq = int_data(rng, nq, d, -1, 2)
+    xq[0] = 0.0; xq[0, 0] = 1.0                        # ascending with ties
+    xq[1] = 0.0; xq[1, 0] = -1.0                       # descending
+    xq[2] = 0.0                                        # all scores equal (zero query): ids 0..k-1 minus the NaN rows
+    D, I = _index(gpu, xb, d).search(xq, k)
+    Dref, Iref = O.flat_search_ip(xb, xq, k)
+    assert not np.isin(I, bad).any()
+    assert np.array_equal(I, Iref) and np.array_equal(D, Dref)
