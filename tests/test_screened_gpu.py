@@ -114,3 +114,19 @@ def test_screen_is_dropped_when_the_corpus_changes(gpu):
         idx.search_screened(idx.prepare_queries(int_data(rng, 1, 768)), 5)
     with pytest.raises(RagrouteHipError):
         _index(gpu, int_data(rng, 100, 768), 768, metric="l2").build_screen()
+
+
+def test_screened_nan_rows_and_large_k(gpu):
+    """NaN rows are never returned (their int8 image is arbitrary, their re-scored value NaN), also at k = 100 with the
+    longest list."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(14)
+    n, d, k = 60_000, 768, 100
+    xb, xq = int_data(rng, n, d), int_data(rng, 9, d)
+    bad = rng.choice(n, size=25, replace=False)
+    xb[bad, 7] = np.nan
+    idx = _index(gpu, xb, d).build_screen(list_len=1024)
+    D, I = idx.search(xq, k)
+    Dref, Iref = O.flat_search_ip(xb, xq, k)
+    assert not np.isin(I, bad).any()
+    assert np.array_equal(I, Iref) and np.array_equal(D, Dref)
