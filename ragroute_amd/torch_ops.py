@@ -4,6 +4,7 @@
     ragroute::l2_normalize_(x) -> x                                                         faiss.normalize_L2, data_source.py:199
     ragroute::merge_topk(D, I, k, descending=True) -> (D, I)                                rerank.py:3-9, 28-34
     ragroute::rows_to_half(x, dim, bf16=False, normalize=False) -> Tensor                   ingest / query conversion
+    ragroute::router_mlp(xq, folded weights..., b3, prob_threshold) -> (logits, mask)       router.py:241-283, 50-55
 
 All take and return CUDA tensors, enqueue on the current stream and never synchronise.  The faiss-shaped classes in
 flat_index.py are thin conveniences over the same entry points (they additionally cache the workspace)."""
@@ -100,3 +101,36 @@ def rows_to_half(x: torch.Tensor, dim: int, bf16: bool = False, normalize: bool 
 @rows_to_half.register_fake
 def _(x, dim, bf16=False, normalize=False):
     return x.new_empty((x.shape[0], dim), dtype=torch.bfloat16 if bf16 else torch.float16)
+
+
+@torch.library.custom_op("ragroute::router_mlp", mutates_args=())
+def router_mlp(xq: torch.Tensor, w1q: torch.Tensor, c1: torch.Tensor, ln1_g: torch.Tensor, ln1_b: torch.Tensor, w2: torch.Tensor,
+               b2: torch.Tensor, ln2_g: torch.Tensor, ln2_b: torch.Tensor, w3: torch.Tensor, model_of_source: torch.Tensor,
+               b3: float, prob_threshold: float) -> tuple[torch.Tensor, torch.Tensor]:
+    """CorpusRoutingNN forward with the folded fc1 (router.py:241-283, 50-55): xq f32 [nq, n_models, d_max], the folded weights
+    of `ragroute_amd.router.fold_weights` (w1q [d_max,256], c1 [C,256], w2 [256,128] = fc2.weight.T, ...), model_of_source
+    int32 [C] -> (logits f32 [nq,C], mask bool [nq,C])."""
+    import ctypes
+    f32 = [xq, w1q, c1, ln1_g, ln1_b, w2, b2, ln2_g, ln2_b, w3]
+    if not all(t.is_cuda and t.dtype == torch.float32 for t in f32) or model_of_source.dtype != torch.int32 or not model_of_source.is_cuda:
+        raise ValueError("router_mlp: float32 CUDA tensors (and an int32 CUDA model_of_source) expected")
+    xq, w1q, c1, ln1_g, ln1_b, w2, b2, ln2_g, ln2_b, w3 = [t.contiguous() for t in f32]
+    mos = model_of_source.contiguous()
+    nq, n_models, d_max = xq.shape
+    C = c1.shape[0]
+    if w1q.shape != (d_max, 256) or c1.shape[1] != 256 or w2.shape != (256, 128) or mos.numel() != C:
+        raise ValueError("router_mlp: weight shapes do not match the folded CorpusRoutingNN layout")
+    st = _lib.RouterWeightsStruct(
+        n_sources=C, d_max=d_max, n_models=n_models, reserved=0, model_of_source=mos.data_ptr(), w1q=w1q.data_ptr(), c1=c1.data_ptr(),
+        ln1_g=ln1_g.data_ptr(), ln1_b=ln1_b.data_ptr(), w2=w2.data_ptr(), b2=b2.data_ptr(), ln2_g=ln2_g.data_ptr(), ln2_b=ln2_b.data_ptr(),
+        w3=w3.data_ptr(), b3=float(b3), prob_threshold=float(prob_threshold), ln_eps=1e-5, reserved2=0.0)
+    logits = torch.empty((nq, C), dtype=torch.float32, device=xq.device)
+    mask = torch.empty((nq, C), dtype=torch.uint8, device=xq.device)
+    with torch.cuda.device(xq.device):
+        check(lib().rr_router_mlp(ctypes.byref(st), xq.data_ptr(), nq, logits.data_ptr(), mask.data_ptr(), _stream()), "rr_router_mlp")
+    return logits, mask.view(torch.bool)
+
+
+@router_mlp.register_fake
+def _(xq, w1q, c1, ln1_g, ln1_b, w2, b2, ln2_g, ln2_b, w3, model_of_source, b3, prob_threshold):
+    return xq.new_empty((xq.shape[0], c1.shape[0]), dtype=torch.float32), xq.new_empty((xq.shape[0], c1.shape[0]), dtype=torch.bool)

@@ -300,3 +300,20 @@ def test_torch_custom_ops(gpu):
     want = x / x.norm(dim=1, keepdim=True)
     torch.ops.ragroute.l2_normalize_(x)
     assert torch.allclose(x, want, atol=1e-6)
+
+
+def test_torch_router_op_equals_router_class(gpu):
+    """torch.ops.ragroute.router_mlp on the folded weights == Router.route_batch (same kernel, same inputs)."""
+    import ragroute_amd.torch_ops  # noqa: F401
+    from ragroute_amd.router import Router
+    case = synth_router_case("medrag", 3, n_queries=20)
+    r = Router("medrag", case["sources"], "ragroute")
+    r.set_router(case["sd"], case["centroids"], *case["scaler"])
+    q = {m: np.stack([qq[m] for qq in case["queries"]]) for m in case["queries"][0]}
+    xq = r.pack_queries(q).to(gpu)
+    logits, mask = r.route_batch(xq)
+    t = r._folded.t
+    sd = case["sd"]
+    l2, m2 = torch.ops.ragroute.router_mlp(xq, t["w1q"], t["c1"], t["ln1_g"], t["ln1_b"], t["w2"], t["b2"], t["ln2_g"], t["ln2_b"], t["w3"],
+                                           t["model_of_source"], float(np.asarray(sd["fc3.bias"]).reshape(-1)[0]), r._folded.struct.prob_threshold)
+    assert torch.equal(l2, logits) and torch.equal(m2, mask)
