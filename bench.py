@@ -4,33 +4,83 @@
 Metric (BASELINE.json): queries/sec for route + top-k (+ merge), d=768 fp16, 10M docs per shard, k=32,
 query batch 256.  One "step" = one pass of the hot path over one batch of 256 synthetic queries:
 router MLP forward (K3) -> query conversion (K0) -> fused similarity scan + top-k over this rank's
-HBM-resident 10M x 768 shard (K1/K2) -> route mask -> [N>1: RCCL all_gather of the (score,id) candidates]
--> cross-shard merge (K4).  One process per GPU; weak scaling: every rank holds its own 10M-row shard and
-every query is answered against all N shards, so the whole job performs N x 256 query-shard searches per
-step and `value` = N * 256 * K / t  (at N=1 exactly queries/sec on one 10M shard).
+HBM-resident shard(s) (K1/K2, route mask folded in) -> [N>1: ONE RCCL all_gather of the packed (score,id)
+candidates] -> cross-shard merge (K4).  One process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+  --scaling weak   (default) every rank holds its own 10M-row shard and every query is answered against all N
+                   shards: the whole job performs N x 256 query-shard searches per step, `value` = N*256*K/t
+                   (at N=1 exactly queries/sec on one 10M shard — the BASELINE configuration).
+  --scaling strong SURVEY.md §8e: the federation is fixed at --total-shards (8) x 10M rows; rank r holds shards
+                   r, r+N, ...; `value` = 256*K/t = queries/sec against the whole 80M-row federation.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself as child processes (the parent never touches the GPU).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16
+METRIC = "queries/sec route+top-k, d=768 fp16, 10M docs/shard, k=32; top-k recall vs CPU"
 
 
-def make_shard(n, d, dim, dtype, seed, dev):
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--total-shards", type=int, default=8, help="--scaling strong: shards of the fixed federation")
+    ap.add_argument("--rows", type=int, default=10_000_000, help="corpus rows per shard")
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--k", type=int, default=32)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0,
+                    help="extra steady-state block after the timed steps (>= this long and >= 500 batches); 0 disables it")
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """--gpus N without a launcher: start the N ranks as CHILD processes (this parent makes no GPU call, not even
+    torch.cuda.is_available()), relay rank 0's JSON line, fail if it does not report n_gpus == N."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        raise SystemExit(f"bench.py: the {args.gpus}-rank run failed (exit code {proc.returncode}, "
+                         f"{'no result line' if line is None else 'result line printed'})")
+    got = json.loads(line).get("n_gpus")
+    if got != args.gpus:
+        print(line)
+        raise SystemExit(f"bench.py: asked for {args.gpus} GPUs but the result line reports n_gpus={got}")
+    print(line, flush=True)
+
+
+def make_shard(torch, n, d, dim, dtype, seed, dev):
     """i.i.d. N(0,1) rows, L2-normalised, cast to the storage dtype — generated on device in chunks."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
@@ -44,24 +94,29 @@ def make_shard(n, d, dim, dtype, seed, dev):
     return xb
 
 
+def percentile(sorted_vals, p):
+    if not sorted_vals:
+        return None
+    i = p * (len(sorted_vals) - 1)
+    lo = int(i)
+    hi = min(lo + 1, len(sorted_vals) - 1)
+    return sorted_vals[lo] + (sorted_vals[hi] - sorted_vals[lo]) * (i - lo)
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rows", type=int, default=10_000_000, help="corpus rows per shard (per GPU)")
-    ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--k", type=int, default=32)
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
     backend = os.environ.get("RR_BENCH_BACKEND", "nccl")  # "gloo" + RR_BENCH_ONE_DEVICE=1 rehearses N>1 on a 1-GPU box
@@ -77,35 +132,43 @@ def main():
 
     from ragroute_amd._lib import check, lib
     from ragroute_amd.flat_index import FlatIndex
+    from ragroute_amd.pipeline import RetrievalPipeline
     from ragroute_amd.router import CorpusRoutingNN, FoldedRouter
 
     d, B, k, n = args.dim, args.batch, args.k, args.rows
     tdt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
-    idx = FlatIndex(d, metric="ip", dtype=args.dtype, device=dev)
-    idx.adopt(make_shard(n, d, idx.dim, tdt, 1234 + rank, dev))
+    strong = args.scaling == "strong"
+    C = args.total_shards if strong else world                     # sources of the federation = router outputs
+    my_shards = list(range(rank, C, world)) if strong else [rank]  # shard s -> GPU s mod G
+    slots = -(-C // world)
+    shards = []
+    for sid in my_shards:
+        idx = FlatIndex(d, metric="ip", dtype=args.dtype, device=dev)
+        idx.adopt(make_shard(torch, n, d, idx.dim, tdt, 1234 + sid, dev))
+        shards.append(idx)
 
     g = torch.Generator(device=dev)
     g.manual_seed(4321)  # same queries on every rank
     xq = torch.randn((B, d), generator=g, device=dev)
     xq /= xq.norm(dim=1, keepdim=True)
 
-    # router: CorpusRoutingNN over C = N sources (one per GPU), default init seed 0, centroid = mean of the
-    # shard's first 100k rows, identity scaler; folded into the fused kernel's weights
-    C = world
-    cen = idx.xb[: min(n, 100_000), :d].float().mean(0)
+    # router: CorpusRoutingNN over the C sources, default init seed 0, centroid = mean of each shard's first 100k rows,
+    # identity scaler; folded into the fused kernel's weights
+    cen_mine = torch.zeros((slots, d), dtype=torch.float32, device=dev)
+    for j, idx in enumerate(shards):
+        cen_mine[j] = idx.xb[: min(n, 100_000), :d].float().mean(0)
     if world > 1:
         on_dev = backend == "nccl"
-        cens = torch.empty(world * d, dtype=torch.float32, device=dev if on_dev else "cpu")
-        dist.all_gather_into_tensor(cens, cen.contiguous().view(-1) if on_dev else cen.cpu().view(-1))
-        cen_all = cens.view(world, d).cpu().numpy()
+        cens = torch.empty(world * slots * d, dtype=torch.float32, device=dev if on_dev else "cpu")
+        dist.all_gather_into_tensor(cens, cen_mine.view(-1) if on_dev else cen_mine.cpu().view(-1))
+        cens = cens.view(world, slots, d).cpu().numpy()
     else:
-        cen_all = cen[None].cpu().numpy()
+        cens = cen_mine[None].cpu().numpy()
+    cen_all = np.stack([cens[s % world, s // world] for s in range(C)]) if strong else np.stack([cens[r, 0] for r in range(world)])
     net = CorpusRoutingNN(2 * d + C, seed=0)
     router = FoldedRouter.fold(net.state_dict(), cen_all, list(range(C)), C, d, [0] * C, 0.5, device=dev)
     xq_router = xq[:, None, :].contiguous()
-
-    from ragroute_amd.pipeline import RetrievalPipeline
-    pipe = RetrievalPipeline([idx], [rank], router=router)
+    pipe = RetrievalPipeline(shards, my_shards, router=router, slots=slots)
 
     def step():  # K3 router -> K0 convert -> K1/K2 scan+top-k (route mask folded in) -> all_gather (N>1) -> K4 merge
         return pipe.search(xq, k, xq_models=xq_router)
@@ -116,80 +179,142 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(n_steps, with_events):
+        """n_steps back-to-back steps: wall clock between two fences (max over ranks), live HIP-event time of every scan
+        launch (rr_profile_*), and optionally one HIP-event pair per step on the launch stream."""
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)] if with_events else []
+        fence()
+        check(lib().rr_profile_begin(n_steps * 8 * len(shards) + 8), "rr_profile_begin")
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            if with_events:
+                evs[i][0].record()
+            step()
+            if with_events:
+                evs[i][1].record()
+        fence()
+        elapsed = time.perf_counter() - t0
+        scan_ms, n_launch, rows_scanned = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
+        check(lib().rr_profile_end(ctypes.byref(scan_ms), ctypes.byref(n_launch), ctypes.byref(rows_scanned)), "rr_profile_end")
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        per_step = sorted(a.elapsed_time(b) for a, b in evs)
+        return elapsed, scan_ms.value, n_launch.value, per_step
+
     for _ in range(args.warmup):
         step()
-    fence()
-    check(lib().rr_profile_begin(args.steps * 16), "rr_profile_begin")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    scan_ms, n_launch, rows_scanned = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
-    check(lib().rr_profile_end(ctypes.byref(scan_ms), ctypes.byref(n_launch), ctypes.byref(rows_scanned)), "rr_profile_end")
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, scan_ms, n_launch, per_step = timed(args.steps, True)
+
+    sustained = None
+    if args.sustained_seconds > 0:
+        est = elapsed / args.steps
+        n_sus = max(500, int(args.sustained_seconds / est) + 1)
+        s_elapsed, s_scan_ms, s_launch, _ = timed(n_sus, False)
+        sustained = (n_sus, s_elapsed, s_scan_ms, s_launch)
 
     if rank == 0:
         K = args.steps
-        ms_per_step = elapsed / K * 1e3
-        value = world * B * K / elapsed
-        alg_bytes = n * d * 2 + B * d * 2 + B * k * 12      # per batch and shard
-        flops = 2.0 * B * n * d
-        launches_per_step = n_launch.value / K
-        avg_launch_ms = scan_ms.value / max(1, n_launch.value)
-        achieved = alg_bytes * K / (scan_ms.value * 1e-3) / 1e9
-        traffic = None
+        S = len(shards)
+        units = B if strong else world * B                 # queries per step the whole job answers (weak: query x shard)
+        alg_bytes = S * (n * d * 2 + B * d * 2 + B * k * 12)  # SURVEY §8(d), per step on this rank
+        flops = 2.0 * B * n * d * S
+        launches_per_step = n_launch / K
+        achieved = alg_bytes * K / (scan_ms * 1e-3) / 1e9
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("rows") == n and tj.get("dim") == d and tj.get("batch") == B:
+            if (tj.get("rows") == n and tj.get("dim") == d and tj.get("batch") == B and tj.get("dtype", "fp16") == args.dtype
+                    and tj.get("k", 32) == k and tj.get("lib_version", lib().rr_version()) == lib().rr_version()):
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = "profiles/traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured in this run)"
+        shape = f"{n} x {d} {args.dtype} rows per shard"
+        layout = (f"{C} shards fixed, {S} per GPU (strong scaling)" if strong else "one shard per GPU (weak scaling)")
         res = {
-            "metric": "queries/sec route+top-k, d=768 fp16, 10M docs/shard, k=32; top-k recall vs CPU",
-            "value": round(value, 1), "unit": "queries/sec", "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{n} x {d} {args.dtype} rows per shard (one shard per GPU), query batch {B}, k={k}, "
-                                   f"exact inner-product top-k + router MLP over {C} source(s) + cross-shard merge",
-                       "rows_per_shard": n, "dim": d, "batch": B, "k": k, "parallelism": f"shard-per-gpu x{world}",
-                       "unit_definition": "query x 10M-row shard searches per second, whole job (N=1: queries/sec on one shard)"},
+            "metric": METRIC, "value": round(units * K / elapsed, 1), "unit": "queries/sec", "n_gpus": world, "steps": K,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "median_ms": round(percentile(per_step, 0.5), 4), "p10_ms": round(percentile(per_step, 0.1), 4),
+            "p90_ms": round(percentile(per_step, 0.9), 4),
+            "config": {"workload": f"{shape}, {layout}, query batch {B}, k={k}, exact inner-product top-k + router MLP over "
+                                   f"{C} source(s) + cross-shard merge",
+                       "rows_per_shard": n, "dim": d, "batch": B, "k": k, "shards_total": C, "shards_per_gpu": S,
+                       "parallelism": f"shard-per-gpu x{world}" if not strong else f"{C} shards over {world} gpu(s)",
+                       "unit_definition": ("queries per second against the whole fixed federation" if strong else
+                                           "query x 10M-row shard searches per second, whole job (N=1: queries/sec on one shard)"),
+                       "timing": "ms_per_step = wall clock of the K steps between fences / K; median/p10/p90 = one HIP-event pair per step"},
             "roofline": {"bound": "hbm", "kernel": "flat_scan16_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": round(alg_bytes / launches_per_step),
-                         "avg_launch_ms": round(avg_launch_ms, 4), "launches_per_step": round(launches_per_step, 2),
-                         "mfma_tflops": round(flops * K / (scan_ms.value * 1e-3) / 1e12, 1),
-                         "mfma_frac": round(flops * K / (scan_ms.value * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                         "scan_share_of_step": round(scan_ms.value / (elapsed * 1e3), 4)},
+                         "avg_launch_ms": round(scan_ms / max(1, n_launch), 4), "launches_per_step": round(launches_per_step, 2),
+                         "mfma_tflops": round(flops * K / (scan_ms * 1e-3) / 1e12, 1),
+                         "mfma_frac": round(flops * K / (scan_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                         "scan_share_of_step": round(scan_ms / (elapsed * 1e3), 4),
+                         "end_to_end_frac": round(alg_bytes * K / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        if sustained is not None:
+            n_sus, s_elapsed, s_scan_ms, s_launch = sustained
+            res["roofline"]["sustained"] = {
+                "batches": n_sus, "seconds": round(s_elapsed, 3), "ms_per_step": round(s_elapsed / n_sus * 1e3, 4),
+                "value": round(units * n_sus / s_elapsed, 1), "avg_launch_ms": round(s_scan_ms / max(1, s_launch), 4),
+                "achieved": round(alg_bytes * n_sus / (s_scan_ms * 1e-3) / 1e9, 1),
+                "frac": round(alg_bytes * n_sus / (s_scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(idx, xq, n, d, k)
+            res["cpu_baseline"] = cpu_baseline(shards[0], xq, n, d, k)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(idx, xq, n, d, k):
     """The reference's CPU call pattern timed on this box's host cores: ONE f32 query per index.search call
-    (data_source.py:113-114,186) over a flat f32 index — the oracle's C restatement ("port": faiss is not installed).
-    Bounded sample: the shard's first 1M rows, as many single-query calls as fit in ~10 s; the rate is scaled
-    linearly in rows to the full shard."""
+    (data_source.py:113-114,186) over a flat f32 index — the oracle's C restatement ("port"), on all usable cores and on
+    one thread.  Bounded sample: the shard's first 1M rows, single-query calls for ~10 s (all cores) + ~5 s (one thread);
+    the rate is scaled linearly in rows to the full shard.  If `import faiss` works on this box, IndexFlatIP.search is
+    timed beside it and compared with the HIP path (the only route to pinning a2/a3)."""
+    import numpy as np
     from oracle import oracle as O
-    # the CPUs this process may really use: affinity mask, capped at the 1-GPU box's CPU share
-    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    O.set_threads(max(1, min(usable, int(os.environ.get("RR_CPU_BASELINE_THREADS", 16)))))
+    cores = max(1, int(os.environ.get("RR_CPU_BASELINE_THREADS", usable_cpus())))
     sample = min(n, 1_000_000)
     xb = idx.xb[:sample, :d].float().cpu().numpy()
     q = xq.cpu().numpy().astype(np.float32)
-    O.flat_search_ip_single(xb, q[0], k)  # warm-up (page-in, thread pool)
-    t0, calls = time.perf_counter(), 0
-    while calls < 256 and (calls < 8 or time.perf_counter() - t0 < 10.0):
-        O.flat_search_ip_single(xb, q[calls % len(q)], k)
-        calls += 1
-    dt = time.perf_counter() - t0
+
+    def rate(threads, budget_s, max_calls):
+        O.set_threads(threads)
+        O.flat_search_ip_single(xb, q[0], k)  # warm-up (page-in, thread pool)
+        t0, calls = time.perf_counter(), 0
+        while calls < max_calls and (calls < 4 or time.perf_counter() - t0 < budget_s):
+            O.flat_search_ip_single(xb, q[calls % len(q)], k)
+            calls += 1
+        dt = time.perf_counter() - t0
+        return calls, dt, O.num_threads()
+
+    calls, dt, used = rate(cores, 10.0, 256)
+    calls1, dt1, _ = rate(1, 5.0, 64)
+    O.set_threads(cores)
     qps_sample = calls / dt
     # parity on the same sample: GPU top-k of the first `sample` rows vs the oracle (f64 scores of the same fp16 values)
     from ragroute_amd.flat_index import FlatIndex
@@ -205,14 +330,54 @@ def cpu_baseline(idx, xq, n, d, k):
               "queries_checked": nchk, "max_abs_score_diff": float(np.abs(Dg - Dr).max()),
               "sample": f"GPU top-{k} of the first {sample} rows vs oracle.flat_search_ip (f64 dot products of the same fp16-rounded values)"}
     extra = cpu_extra_rows(O, xb, q, k, sample, n)
-    return {"value": round(qps_sample * sample / n, 3), "unit": "queries/sec", "cores": O.num_threads(), "kind": "port",
-            "sample": f"{calls} single-query f32 searches (nq=1 per call, as the reference issues them) over the first {sample} rows "
-                      f"in {dt:.2f} s = {qps_sample:.2f} q/s on the sample, scaled x{sample / n:.3g} to {n} rows",
-            "parity_vs_cpu": parity, "other_rows": extra}
+    out = {"value": round(qps_sample * sample / n, 3), "unit": "queries/sec", "cores": used, "kind": "port",
+           "sample": f"{calls} single-query f32 searches (nq=1 per call, as the reference issues them) over the first {sample} rows "
+                     f"in {dt:.2f} s = {qps_sample:.2f} q/s on the sample, scaled x{sample / n:.3g} to {n} rows; "
+                     f"{used} OpenMP threads = every CPU this process may use",
+           "one_thread": {"value": round(calls1 / dt1 * sample / n, 4), "cores": 1,
+                          "sample": f"{calls1} searches in {dt1:.2f} s on the same sample, same scaling"},
+           "parity_vs_cpu": parity, "other_rows": extra}
+    out.update(faiss_probe(xb, q, qh, Dg, Ig, k, sample, n))
+    return out
+
+
+def faiss_probe(xb, q, qh, Dg, Ig, k, sample, n):
+    """BASELINE.md row C5 / SURVEY §8d: if faiss happens to be installed on this box, time IndexFlatIP.search at nq = 1 on the
+    same sample and compare its results with the HIP path's (parity_vs_faiss); otherwise say so.  Nothing is installed."""
+    import numpy as np
+    try:
+        import faiss  # noqa: F401
+    except Exception as e:  # ImportError, or a broken wheel
+        return {"faiss": "unavailable", "faiss_detail": f"import faiss: {type(e).__name__}"}
+    index = faiss.IndexFlatIP(xb.shape[1])
+    index.add(xb)
+    index.search(q[:1], k)
+    t0, calls = time.perf_counter(), 0
+    while calls < 256 and (calls < 8 or time.perf_counter() - t0 < 5.0):
+        index.search(q[calls % len(q)][None, :], k)
+        calls += 1
+    dt = time.perf_counter() - t0
+    Df, If = index.search(np.ascontiguousarray(qh), k)
+    gaps_ok = np.ones_like(If, dtype=bool)
+    gaps_ok[:, 1:] &= (Df[:, :-1] - Df[:, 1:]) > 2e-3
+    gaps_ok[:, :-1] &= (Df[:, :-1] - Df[:, 1:]) > 2e-3
+    x = np.ascontiguousarray(q[:64].copy())
+    y = x.copy()
+    faiss.normalize_L2(x)
+    from ragroute_amd.flat_index import normalize_L2
+    normalize_L2(y)
+    return {"faiss": getattr(faiss, "__version__", "present"),
+            "C5_faiss_IndexFlatIP_nq1": {"value": round(calls / dt * sample / n, 3), "unit": "queries/sec",
+                                         "sample": f"{calls} nq=1 searches over {sample} rows in {dt:.2f} s, scaled x{sample / n:.3g}",
+                                         "threads": faiss.omp_get_max_threads()},
+            "parity_vs_faiss": {"ids_identical_where_gap_gt_2e-3": bool(np.array_equal(Ig[gaps_ok], If[gaps_ok])),
+                                "positions_compared": int(gaps_ok.sum()), "max_abs_score_diff": float(np.abs(Dg - Df).max()),
+                                "score_tolerance": 1e-3, "normalize_L2_max_abs_diff": float(np.abs(x - y).max())}}
 
 
 def cpu_extra_rows(O, xb, q, k, sample, n):
     """BASELINE.md rows C2-C4 on the same host cores (context only): batched sgemm + top-k, router forward, merge."""
+    import numpy as np
     t0 = time.perf_counter()
     S = q @ xb.T                                             # C2: nq = 256 blocked sgemm (numpy BLAS) + per-query top-k
     idx = np.argpartition(-S, k, axis=1)[:, :k]

@@ -1,31 +1,118 @@
-"""Build libragroute_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build()."""
+"""Build libragroute_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build().
+
+Every translation unit is compiled to its own object (in parallel, only when it or a header changed), the objects are linked
+into the shared library, and the device code of flat_scan_wide.hip is then disassembled and checked (check_isa): the wide-row
+kernel keeps its accumulators in hard-wired AGPRs that the compiler only knows as asm clobbers, so a compiler-made
+AGPR copy or a scratch spill inside that kernel would silently corrupt scores — the build fails instead."""
+import concurrent.futures
 import os
+import re
 import subprocess
 
-CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libragroute_hip.so")
-SOURCES = ["capi.hip", "flat_scan.hip", "flat_scan_dev.hip", "select.hip", "prep.hip", "router.hip", "screen.hip"]
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+OBJ_DIR = os.path.join(CSRC, "build")
+LIB_PATH = os.path.join(PKG, "libragroute_hip.so")
+SOURCES = ["capi.hip", "flat_scan.hip", "flat_scan_wide.hip", "flat_scan_dev.hip", "select.hip", "prep.hip", "router.hip", "screen.hip"]
+HEADERS = ["rr_common.h", "rr_kernels.h", "rr_sort.h", "flat_scan_common.h"]
+LLVM_BIN = os.environ.get("RR_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+
+# kernels whose accumulators live in hard-wired AGPRs named only inside asm text
+FIXED_AGPR_KERNELS = ("flat_scan_wide_kernel",)
+
+
+def _flags():
+    flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"]
+    if os.environ.get("RR_DEV_VARIANTS") or os.environ.get("RR_ABLATION_VARIANTS"):
+        flags.append("-DRR_DEV_VARIANTS")      # the measured alternatives of flat_scan_dev.hip (RR_SCAN_VARIANT / RR_GENERIC_TALL)
+    if os.environ.get("RR_ABLATION_VARIANTS"):
+        flags.append("-DRR_ABLATION_VARIANTS")  # + timing-only ablations of the 32x32x16 loop
+    if os.environ.get("RR_EXTRA_DEFINES"):      # development A/B builds, e.g. "-DRR_DMA_SCHED=1"
+        flags += os.environ["RR_EXTRA_DEFINES"].split()
+    return flags
+
+
+def _run(cmd, what):
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"{what} failed:\n{' '.join(cmd)}\n{res.stdout[-2000:]}{res.stderr[-4000:]}")
+    return res
+
+
+def device_code_object(obj_path, out_path):
+    """Extract the gfx950 code object embedded in a HIP object file."""
+    fat = out_path + ".fatbin"
+    _run([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", obj_path], "llvm-objcopy")
+    _run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--unbundle", f"--input={fat}", "--type=o",
+          "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={out_path}"], "clang-offload-bundler")
+    os.remove(fat)
+    return out_path
+
+
+def check_isa(obj_path):
+    """Fail if a kernel with hard-wired AGPR accumulators contains anything the compiler could only have put there by
+    treating those AGPRs (or scratch) as its own: v_accvgpr_write / v_accvgpr_mov (AGPR spills and copies; the kernel's own
+    asm only ever READS accumulators with v_accvgpr_read), scratch_ instructions, a private segment, or spill counts."""
+    co = device_code_object(obj_path, obj_path + ".gfx950.co")
+    notes = _run([os.path.join(LLVM_BIN, "llvm-readelf"), "--notes", co], "llvm-readelf").stdout
+    problems, seen = [], 0
+    for block in notes.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block)
+        if not name or not any(k in name.group(1) for k in FIXED_AGPR_KERNELS):
+            continue
+        seen += 1
+        for key in (".private_segment_fixed_size", ".vgpr_spill_count", ".sgpr_spill_count"):
+            m = re.search(re.escape(key) + r":\s+(\d+)", block)
+            if m and int(m.group(1)) != 0:
+                problems.append(f"{name.group(1)}: {key} = {m.group(1)}")
+    dis = _run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", "--no-show-raw-insn", co], "llvm-objdump").stdout
+    current = None
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            current = m.group(1) if any(k in m.group(1) for k in FIXED_AGPR_KERNELS) else None
+            continue
+        if current and re.search(r"\b(v_accvgpr_write|v_accvgpr_mov|scratch_load|scratch_store)", line):
+            problems.append(f"{current}: {line.strip()}")
+    os.remove(co)
+    if seen == 0:
+        problems.append("no kernel named " + " / ".join(FIXED_AGPR_KERNELS) + " found in the device code")
+    if problems:
+        raise RuntimeError("ISA check of the fixed-AGPR kernels failed (the compiler used AGPRs or scratch of its own):\n  " +
+                           "\n  ".join(problems[:40]))
+    return seen
 
 
 def build(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("rr_common.h", "rr_kernels.h", "rr_sort.h", "flat_scan_common.h")] + [
-        os.path.join(os.path.dirname(CSRC), "..", "include", "ragroute_hip.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    suffix = os.environ.get("RR_LIB_SUFFIX", "")
+    lib_path = LIB_PATH.replace(".so", suffix + ".so") if suffix else LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-o", LIB_PATH] + srcs
-    if os.environ.get("RR_DEV_VARIANTS") or os.environ.get("RR_ABLATION_VARIANTS"):
-        cmd.insert(1, "-DRR_DEV_VARIANTS")      # the measured alternatives of flat_scan_dev.hip (RR_SCAN_VARIANT / RR_GENERIC_TALL)
-    if os.environ.get("RR_ABLATION_VARIANTS"):
-        cmd.insert(1, "-DRR_ABLATION_VARIANTS")  # + timing-only ablations of the 32x32x16 loop
-    if os.environ.get("RR_EXTRA_DEFINES"):  # development A/B builds, e.g. "-DRR_DMA_SCHED=1"
-        cmd[1:1] = os.environ["RR_EXTRA_DEFINES"].split()
-    if os.environ.get("RR_LIB_SUFFIX"):
-        cmd[cmd.index("-o") + 1] = LIB_PATH.replace(".so", os.environ["RR_LIB_SUFFIX"] + ".so")
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if verbose or res.returncode != 0:
-        print(res.stdout, res.stderr)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed building libragroute_hip.so:\n" + res.stderr[-4000:])
-    return LIB_PATH
+    flags = _flags()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    headers = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(PKG, "..", "include", "ragroute_hip.h")]
+    hdr_time = max(os.path.getmtime(h) for h in headers)
+    stamp = os.path.join(OBJ_DIR, f"flags{suffix}.txt")
+    flags_changed = not os.path.exists(stamp) or open(stamp).read() != " ".join(flags)
+    jobs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ_DIR, s.replace(".hip", suffix + ".o"))
+        stale = force or flags_changed or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time)
+        jobs.append((src, obj, stale))
+    todo = [(src, obj) for src, obj, stale in jobs if stale]
+    if not todo and os.path.exists(lib_path) and all(os.path.getmtime(lib_path) >= os.path.getmtime(o) for _, o, _ in jobs):
+        return lib_path
+
+    def compile_one(job):
+        src, obj = job
+        res = _run([hipcc] + flags + ["-c", src, "-o", obj], f"hipcc -c {os.path.basename(src)}")
+        return res.stderr
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as pool:
+        for err in pool.map(compile_one, todo):
+            if verbose and err:
+                print(err)
+    open(stamp, "w").write(" ".join(flags))
+    check_isa(os.path.join(OBJ_DIR, "flat_scan_wide" + suffix + ".o"))
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + [o for _, o, _ in jobs], "hipcc -shared")
+    return lib_path

@@ -438,246 +438,6 @@ __global__ __launch_bounds__(256, 1) void flat_scan16h_kernel(const ScanArgs a) 
   }
 }
 
-// ---- wide rows (d > 1536, any multiple of 128), hand-pipelined -------------------------------------------------------
-// The transposed design of flat_scan16_kernel: there the QUERIES stay in registers and the corpus streams past; here rows
-// are too wide for that, so the ACCUMULATORS stay (all 256 AGPRs: 256 rows x 64 queries per wave) and both operands stream
-// in 64-wide K steps: corpus slab (NT 32-row tiles x 128 B = 32 KB) HBM -> LDS by LDS-DMA through a 3-slot ring (two K
-// steps ahead), the wave's 64 queries x 128 B from L2 straight into registers one K step ahead (scalar base + lane offset
-// loads, double-buffered; every CU re-reads the query block once per 256 rows: 1 B of L2 traffic per corpus byte).
-// Per K step and wave: 32 A fragments (ring of 8 ds_read_b128) x 4 MFMA 16x16x32, 8 DMA pieces, 8 query loads.
-// The LDS image of a slab is NT copies of flat_scan16_kernel's 4 KB k-group block, so addressing is shared.
-// vmcnt queue at the top of step s (oldest first): DMA(s) | q(s), DMA(s+1) -> wait vmcnt(NT): only DMA(s+1) may be out.
-// Accumulators are HARD-WIRED AGPRs a[4i .. 4i+3]: 64 tied "+a" operands (256 registers) defeat hipcc's allocator (it
-// shuttled them through scratch and v_accvgpr_mov at every loop edge).  Every statement that touches them names all 256 as
-// clobbers, so the compiler keeps nothing of its own in AGPRs and sizes the kernel's register file for them.
-#define RR_ALL_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
-template <typename T> struct Mfma16Fixed;
-#define RR_MFMA16F(NAME, MNEMONIC, FRAG)                                                                             \
-  template <> struct Mfma16Fixed<NAME> {                                                                             \
-    template <int R, bool FIRST>                                                                                     \
-    static __device__ __forceinline__ void run(FRAG a, FRAG b) {                                                     \
-      if (FIRST) asm volatile(MNEMONIC " a[%2:%3], %0, %1, 0" ::"v"(a), "v"(b), "n"(R), "n"(R + 3) : RR_ALL_AGPRS);  \
-      else asm volatile(MNEMONIC " a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "n"(R), "n"(R + 3) : RR_ALL_AGPRS); \
-    }                                                                                                                \
-  };
-RR_MFMA16F(_Float16, "v_mfma_f32_16x16x32_f16", f16x8)
-RR_MFMA16F(__bf16, "v_mfma_f32_16x16x32_bf16", bf16x8)
-#undef RR_MFMA16F
-template <int R>
-__device__ __forceinline__ f32x4 read_acc_fixed() {
-  f32x4 v;
-  asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
-               : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]) : "n"(R), "n"(R + 1), "n"(R + 2), "n"(R + 3) : RR_ALL_AGPRS);
-  return v;
-}
-
-template <typename F>
-__device__ __forceinline__ void query_load_frag(F& dst, uint32_t lane_off, const void* sbase, int imm) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(lane_off), "s"(sbase), "n"(imm) : "memory");
-}
-
-// (Carrying the fragment ring across K steps - 4 slots, the barrier moved to fragment 24 of the step before - measured 3.53 vs
-// 3.66 TB/s: no gain, like the same experiment on flat_scan16_kernel; not kept.)
-template <int N, typename F>
-__device__ __forceinline__ void vm_wait_tied8(F& r0, F& r1, F& r2, F& r3, F& r4, F& r5, F& r6, F& r7) {
-  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "n"(N) : "memory");
-}
-// DENSE launches (bootstrap sample, corpora <= 8192 rows) cover at most 256 tiles: with 8-tile groups only 32 workgroups would
-// have work and each would still walk the whole K loop (112 us at d = 4096), so they use one tile per group.
-template <typename T, bool DENSE, bool L2 = false>
-__global__ __launch_bounds__(256, 1) void flat_scan_wide_kernel(const ScanArgs a, const int D) {
-  typedef typename Mfma<T>::frag frag;
-  constexpr int NT = DENSE ? 1 : 8;        // 32-row tiles per group
-  constexpr int STEP_BYTES = NT * 4096;    // one K step of one group in LDS
-  constexpr int NS = 3;
-  constexpr int LEAD = NS - 1;             // K steps the DMA stream runs ahead
-  constexpr int NF = 4 * NT;               // A fragments per K step: (tile, s2, rb)
-  constexpr int NB = NF < 8 ? NF : 8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int col = lane & 15, g = lane >> 4;
-  const int KG = D / 64;                   // even (D is a multiple of 128)
-  const uint32_t n_tiles = a.n_tiles;
-  const uint32_t n_groups = (n_tiles + NT - 1) / NT;
-
-  uint32_t roff[2];
-  {
-    const int rho = col & 7, p = col >> 3;
-    const int f = ((rho >> 1) & 3) | (p << 2);
-#pragma unroll
-    for (int par = 0; par < 2; ++par) roff[par] = p * 1024 + rho * 128 + (((4 * par + g) ^ f) * 16);
-  }
-  // DMA side: this wave's piece of tile t = rows 8*wave .. +7, lane -> (row rho_w, 16-byte chunk c_w)
-  const int rho_w = lane >> 3, sig = lane & 7;
-  const int f_w = ((rho_w >> 1) & 3) | ((wave & 1) << 2);
-  const int c_w = sig ^ f_w;
-  const size_t row_bytes = (size_t)D * 2;
-  auto issue_piece = [&](uint32_t grp, int kg, int slot, int t) {
-    uint32_t j = grp * NT + t;
-    j = j < n_tiles ? j : n_tiles - 1;
-    uint32_t row = (a.tile_first + j * a.tile_stride) * kTileRows + wave * 8 + rho_w;
-    row = row < a.n_rows ? row : a.n_rows - 1;
-    const char* gp = (const char*)a.xb + (size_t)row * row_bytes + (size_t)kg * 128 + c_w * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                     (__attribute__((address_space(3))) void*)(smem + slot * STEP_BYTES + t * 4096 + wave * 1024), 16, 0, 2);
-  };
-
-  const int nb = __builtin_amdgcn_readfirstlane(
-      (int)a.nq <= wave * 64 ? 0 : ((int)a.nq - wave * 64 >= 64 ? 4 : ((int)a.nq - wave * 64 + 15) / 16));
-  uint32_t qoff[4];
-#pragma unroll
-  for (int qb = 0; qb < 4; ++qb) {
-    const uint32_t qi = wave * 64 + qb * 16 + col;
-    qoff[qb] = (qi < a.nq ? qi : a.nq - 1) * (uint32_t)(D * 2) + 16 * g;
-  }
-  LaneState4 st;
-  const uint32_t nbuf = gridDim.x * 4;
-#pragma unroll
-  for (int qb = 0; qb < 4; ++qb) {
-    const uint32_t qi = wave * 64 + qb * 16 + col;
-    st.thr[qb] = DENSE ? 0.f : a.thr[qi];
-    st.cnt[qb] = 0;
-    st.off[qb] = (qi * nbuf + blockIdx.x * 4 + g) * (uint32_t)a.cap;
-  }
-
-  uint32_t grp = blockIdx.x;               // group being multiplied
-  uint32_t dgrp = blockIdx.x;              // group / K step the DMA stream is at (two steps ahead)
-  int dkg = 0, dslot = 0;
-  auto dma_advance = [&]() {
-    if (++dkg == KG) { dkg = 0; dgrp += gridDim.x; }
-    if (++dslot == NS) dslot = 0;
-  };
-  auto mfma4 = [&](auto r_tag, auto first_tag, frag x, frag q0, frag q1, frag q2, frag q3) {
-    constexpr int R = decltype(r_tag)::value;
-    constexpr bool F1 = decltype(first_tag)::value;
-    Mfma16Fixed<T>::template run<R, F1>(x, q0);
-    Mfma16Fixed<T>::template run<R + 4, F1>(x, q1);
-    Mfma16Fixed<T>::template run<R + 8, F1>(x, q2);
-    Mfma16Fixed<T>::template run<R + 12, F1>(x, q3);
-  };
-  auto read_tile = [&](auto r_tag, f32x4 (&e)[2][4]) {
-    constexpr int R = decltype(r_tag)::value;
-    e[0][0] = read_acc_fixed<R>();      e[0][1] = read_acc_fixed<R + 4>();  e[0][2] = read_acc_fixed<R + 8>();  e[0][3] = read_acc_fixed<R + 12>();
-    e[1][0] = read_acc_fixed<R + 16>(); e[1][1] = read_acc_fixed<R + 20>(); e[1][2] = read_acc_fixed<R + 24>(); e[1][3] = read_acc_fixed<R + 28>();
-  };
-  frag q[2][4][2];                         // [buffer][query block][k slice]
-  // The query loads are asynchronous asm: their destination registers must have LANDED before any point where hipcc may
-  // copy them (it inserts v_mov copies of loop-carried values at loop back-edges).  So the wait for the queries of step
-  // s+1 closes step s, and the statement names the registers as in/out operands: every later use or copy follows it.
-  auto queries_landed = [&](auto buf_tag) {
-    constexpr int B = decltype(buf_tag)::value;
-    vm_wait_tied8<NT>(q[B][0][0], q[B][0][1], q[B][1][0], q[B][1][1], q[B][2][0], q[B][2][1], q[B][3][0], q[B][3][1]);
-  };
-  auto load_queries = [&](int buf, int kg) {
-    const char* sb = (const char*)a.xq + (size_t)kg * 128;
-#pragma unroll
-    for (int qb = 0; qb < 4; ++qb) {
-      query_load_frag(q[buf][qb][0], qoff[qb], sb, 0);
-      query_load_frag(q[buf][qb][1], qoff[qb], sb, 64);
-    }
-  };
-  if (grp < n_groups) {
-    // prologue, in the steady-state queue order: DMA(0) [, DMA(1)] | q(0), DMA(LEAD-1)
-#pragma unroll
-    for (int sidx = 0; sidx < LEAD - 1; ++sidx) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) issue_piece(dgrp, dkg, dslot, t);
-      dma_advance();
-    }
-    load_queries(0, 0);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) issue_piece(dgrp, dkg, dslot, t);
-    dma_advance();
-    queries_landed(std::integral_constant<int, 0>{});   // only DMA(LEAD-1) may still be in flight
-  }
-
-  int slot = 0;   // accumulator of (tile t, row block rb, query block qb): a[16 (2t + rb) + 4 qb ..+3]
-  while (grp < n_groups) {
-    for (int kg = 0; kg < KG; kg += 2) {
-      auto step = [&](auto buf_tag, auto first_tag, int kgs) {
-        constexpr int P = decltype(buf_tag)::value;
-        constexpr bool FIRST = decltype(first_tag)::value;
-        // (this step's queries and, older in the queue, its slab pieces were waited for when the previous step closed)
-        __builtin_amdgcn_s_barrier();
-        {
-          int nkg = kgs + 1;
-          if (nkg == KG) nkg = 0;          // the next group starts over on the same queries
-          load_queries(1 - P, nkg);
-        }
-        if (nb > 0) {
-          frag c[NB];
-          const uint32_t ab0 = (uint32_t)(slot * STEP_BYTES) + roff[0], ab1 = (uint32_t)(slot * STEP_BYTES) + roff[1];
-          // fragment f: tile f>>2, k slice (f>>1)&1, row block f&1
-#pragma unroll
-          for (int f = 0; f < NB; ++f) lds_read_frag(c[f], ((f >> 1) & 1) ? ab1 : ab0, (f >> 2) * 4096 + (f & 1) * 2048);
-          static_for<NF>([&](auto fi) {
-            constexpr int f = decltype(fi)::value;
-            constexpr int t = f >> 2, par = (f >> 1) & 1, rb = f & 1;
-            if (NF - f >= NB) lgkm_wait<NB - 1>();
-            else if (NF - f == 7) lgkm_wait<6>();
-            else if (NF - f == 6) lgkm_wait<5>();
-            else if (NF - f == 5) lgkm_wait<4>();
-            else if (NF - f == 4) lgkm_wait<3>();
-            else if (NF - f == 3) lgkm_wait<2>();
-            else if (NF - f == 2) lgkm_wait<1>();
-            else lgkm_wait<0>();
-            mfma4(std::integral_constant<int, 16 * (2 * t + rb)>{}, std::integral_constant<bool, FIRST && par == 0>{}, c[f % NB],
-                  q[P][0][par], q[P][1][par], q[P][2][par], q[P][3][par]);
-            if (f + NB < NF) {
-              constexpr int fn = f + NB;
-              lds_read_frag(c[f % NB], ((fn >> 1) & 1) ? ab1 : ab0, (fn >> 2) * 4096 + (fn & 1) * 2048);
-            }
-            if ((f & 3) == 1) issue_piece(dgrp, dkg, dslot, f >> 2);
-          });
-        } else {
-#pragma unroll
-          for (int t = 0; t < NT; ++t) issue_piece(dgrp, dkg, dslot, t);
-        }
-        dma_advance();
-        if (++slot == NS) slot = 0;
-        queries_landed(std::integral_constant<int, 1 - P>{});  // queue: ... q(s+1) | DMA(s+LEAD): NT pieces may remain
-      };
-      if (kg == 0) step(std::integral_constant<int, 0>{}, std::true_type{}, kg);
-      else step(std::integral_constant<int, 0>{}, std::false_type{}, kg);
-      step(std::integral_constant<int, 1>{}, std::false_type{}, kg + 1);
-    }
-    if (nb > 0) {
-      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      static_for<NT>([&](auto ti) {
-        constexpr int t = decltype(ti)::value;
-        const uint32_t j = grp * NT + t;
-        if (j < n_tiles) {
-          f32x4 e[2][4];
-          read_tile(std::integral_constant<int, 32 * t>{}, e);
-          if (L2) {  // rank by q.x - |x|^2/2: the lane's 2 x 4 rows of this tile (rows past the end are filtered by id later)
-            const uint32_t r0 = (a.tile_first + j * a.tile_stride) * kTileRows + 4 * g;
-            f32x4 h0, h1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              h0[i] = a.half_sqnorm[r0 + i < a.n_rows ? r0 + i : a.n_rows - 1];
-              h1[i] = a.half_sqnorm[r0 + 16 + i < a.n_rows ? r0 + 16 + i : a.n_rows - 1];
-            }
-#pragma unroll
-            for (int qb = 0; qb < 4; ++qb) {
-              e[0][qb] -= h0;
-              e[1][qb] -= h1;
-            }
-          }
-          tile_epilogue16<DENSE, 4>(a, st, e, j, lane, wave);
-        }
-      });
-    }
-    grp += gridDim.x;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
-  if (!DENSE) {
-#pragma unroll
-    for (int qb = 0; qb < 4; ++qb) a.cand_cnt[(wave * 64 + qb * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
-  }
-}
-
 template <typename T, int D>
 static hipError_t launch_scan16h(const ScanArgs& a, bool dense, int grid, hipStream_t st) {
   constexpr int unit = 16 * D * 2;
@@ -705,23 +465,6 @@ static hipError_t launch_scan_half_resident(const ScanArgs& a, int D, bool dense
     case 1536: return launch_scan16h<T, 1536>(a, dense, grid, st);
     default: return hipErrorInvalidValue;
   }
-}
-
-template <typename T>
-static hipError_t launch_scan_wide(const ScanArgs& a, int D, bool dense, int grid, hipStream_t st) {
-  if (D % 128 != 0) return hipErrorInvalidValue;
-  const size_t lds = 3 * (dense ? 1 : 8) * 4096;
-  hipError_t e;
-#define RR_LAUNCH_W(DENSE_, L2_)                                                                                             \
-  {                                                                                                                         \
-    e = hipFuncSetAttribute((const void*)flat_scan_wide_kernel<T, DENSE_, L2_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    if (e != hipSuccess) return e;                                                                                          \
-    hipLaunchKernelGGL((flat_scan_wide_kernel<T, DENSE_, L2_>), dim3(grid), dim3(256), lds, st, a, D);                     \
-  }
-  if (a.half_sqnorm) { if (dense) RR_LAUNCH_W(true, true) else RR_LAUNCH_W(false, true) }
-  else { if (dense) RR_LAUNCH_W(true, false) else RR_LAUNCH_W(false, false) }
-#undef RR_LAUNCH_W
-  return hipGetLastError();
 }
 
 int g_wide_min_queries = 129;  // 768 < D <= 1536: batches of at least this many queries take the wide-row kernel in one pass (RR_WIDE_MIN_QUERIES)
@@ -818,8 +561,8 @@ hipError_t launch_flat_scan(const ScanArgs& a, int dtype, int D, bool dense, int
   const bool f16 = dtype == RR_DTYPE_F16;
   if (half_resident_dim(D) && (int)a.nq < g_wide_min_queries && !a.half_sqnorm)  // 768 < D <= 1536, small batch: 32 resident queries per wave
     return f16 ? launch_scan_half_resident<_Float16>(a, D, dense, grid, st) : launch_scan_half_resident<__bf16>(a, D, dense, grid, st);
-  if (D > kMaxResidentDim)  // wide rows; at 768 < D <= 1536 one pass of this kernel beats two passes of the half-resident one
-    return f16 ? launch_scan_wide<_Float16>(a, D, dense, grid, st) : launch_scan_wide<__bf16>(a, D, dense, grid, st);
+  if (D > kMaxResidentDim)  // wide rows (flat_scan_wide.hip); at 768 < D <= 1536 one pass of it beats two passes of the half-resident kernel
+    return launch_scan_wide(a, dtype, D, dense, grid, st);
   return f16 ? launch_scan_d<_Float16>(a, D, dense, grid, st) : launch_scan_d<__bf16>(a, D, dense, grid, st);
 }
 

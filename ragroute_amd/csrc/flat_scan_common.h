@@ -326,6 +326,9 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 // B=256, -11 % for single-query searches); smaller ones keep the default policy so back-to-back searches stay on die.
 constexpr size_t kNtThresholdBytes = 256ull << 20;
 
+// flat_scan_wide.hip
+hipError_t launch_scan_wide(const ScanArgs& a, int dtype, int D, bool dense, int grid, hipStream_t st);
+
 // flat_scan_dev.hip (only in builds with -DRR_DEV_VARIANTS): the development kernels behind RR_SCAN_VARIANT / RR_GENERIC_TALL
 bool dev_scan_handles(const ScanArgs& a, int D, int variant, int tall);
 int dev_scan_bufs_per_wg(int D, int variant, int tall);

@@ -18,28 +18,58 @@ from .flat_index import FlatIndex, normalize_L2
 logger = logging.getLogger("client")
 
 
+_FLAT_FOURCC = {b"IxFI": 0, b"IxF2": 1}   # IndexFlatIP -> METRIC_INNER_PRODUCT, IndexFlatL2 -> METRIC_L2
+
+
 def read_faiss_flat_index(path, mmap=True):
-    """Minimal reader for a FAISS IndexFlat file ("IxFI"/"IxF2"): returns (float32 [ntotal,d], metric).
+    """Minimal reader for a FAISS IndexFlat file: returns (float32 [ntotal,d], "ip" | "l2") — what `faiss.read_index`
+    (data_source.py:71) yields for the flat indexes the scan kernel replaces.
     With mmap=True (default) the payload is memory-mapped, so a 70 GB index (MedRAG pubmed: 23.9 M x 768 f32) is streamed
     into HBM chunk by chunk by FlatIndex.add instead of being loaded into host RAM first.
-    Layout per FAISS's index_write.cpp (1.7.x): fourcc, d:i32, ntotal:i64, 2 x i64 dummy, is_trained:u8,
-    metric_type:i32 [, metric_arg:f32 if metric_type > 1], then size:u64 (in floats) + payload.
-    Format knowledge is external to the reference tree and unverified against a real faiss file here."""
+
+    Layout (FAISS 1.7.x impl/index_write.cpp, `write_index_header` + the IndexFlat branch; little endian):
+        fourcc        4 B   "IxFI" (inner product) | "IxF2" (L2) | "IxFl" (IndexFlat with another metric)
+        d             i32
+        ntotal        i64
+        dummy, dummy  2 x i64 (1 << 20)
+        is_trained    u8
+        metric_type   i32   0 = METRIC_INNER_PRODUCT, 1 = METRIC_L2, > 1 = other metrics, followed by
+        [metric_arg   f32   only when metric_type > 1]
+        size          u64   payload length in 4-byte units (= ntotal * d)
+        payload       size x f32, row-major
+    Anything else — a non-flat index (HNSW, IVF, PQ ...), a metric other than IP / L2, a header that contradicts its
+    fourcc or its payload — raises ValueError, which the service loop logs (data_source.py:137-138).
+    The layout is external knowledge (faiss is not in the reference tree nor in this image): byte-level fixtures in
+    tests/test_faiss_file_format.py restate it independently of the writer below."""
     with open(path, "rb") as f:
-        fourcc = f.read(4)
-        if fourcc not in (b"IxFI", b"IxF2", b"IxFl"):
-            raise ValueError(f"{path}: not a flat FAISS index (fourcc {fourcc!r}); only IndexFlat files are supported")
-        d = int(np.frombuffer(f.read(4), np.int32)[0])
-        ntotal = int(np.frombuffer(f.read(8), np.int64)[0])
-        f.read(16)
-        f.read(1)
-        metric_type = int(np.frombuffer(f.read(4), np.int32)[0])
-        if metric_type > 1:
-            f.read(4)
-        nfloat = int(np.frombuffer(f.read(8), np.uint64)[0])
+        head = f.read(4 + 4 + 8 + 16 + 1 + 4)
+        if len(head) < 4:
+            raise ValueError(f"{path}: not a FAISS index file (shorter than a fourcc)")
+        fourcc = head[:4]
+        if fourcc not in _FLAT_FOURCC and fourcc != b"IxFl":
+            raise ValueError(f"{path}: not a flat FAISS index (fourcc {fourcc!r}); only IndexFlatIP / IndexFlatL2 files are supported")
+        if len(head) < 37:
+            raise ValueError(f"{path}: truncated IndexFlat header")
+        d = int(np.frombuffer(head, np.int32, 1, 4)[0])
+        ntotal = int(np.frombuffer(head, np.int64, 1, 8)[0])
+        metric_type = int(np.frombuffer(head, np.int32, 1, 33)[0])
+        if metric_type not in (0, 1):
+            raise ValueError(f"{path}: metric_type {metric_type} is not supported (only 0 = inner product and 1 = L2)")
+        if fourcc in _FLAT_FOURCC and _FLAT_FOURCC[fourcc] != metric_type:
+            raise ValueError(f"{path}: fourcc {fourcc!r} contradicts metric_type {metric_type}")
+        if d <= 0 or ntotal < 0:
+            raise ValueError(f"{path}: bad header (d={d}, ntotal={ntotal})")
+        size = f.read(8)
+        if len(size) < 8:
+            raise ValueError(f"{path}: truncated IndexFlat header")
+        nfloat = int(np.frombuffer(size, np.uint64)[0])
         if nfloat != ntotal * d:
             raise ValueError(f"{path}: payload of {nfloat} floats does not match ntotal*d = {ntotal * d}")
         offset = f.tell()
+        f.seek(0, 2)
+        if f.tell() - offset < nfloat * 4:
+            raise ValueError(f"{path}: file holds {f.tell() - offset} payload bytes, header promises {nfloat * 4}")
+        f.seek(offset)
         if mmap and ntotal > 0:
             xb = np.memmap(path, dtype=np.float32, mode="r", offset=offset, shape=(ntotal, d))
         else:
@@ -123,8 +153,6 @@ class DataSource:
             index = xb
         else:
             metric = getattr(self, "index_metric", "ip")
-            if metric == "l2" and xb.shape[1] > 768:
-                raise NotImplementedError("L2 flat indexes wider than 768 are not supported yet")
             index = FlatIndex(xb.shape[1], metric=metric, dtype=self.dtype)
             index.reserve(xb.shape[0])
             index.add(xb)
@@ -215,37 +243,71 @@ class DataSource:
                 "scores": scores, "duration": time.time() - start_time}
 
     # -- service loop (transport glue; needs pyzmq like the reference) ----------------------------------
-    async def start(self):  # pragma: no cover - needs pyzmq
+    async def start(self):
+        """data_source.py:82-141: bind PULL :6000+i, connect PUSH :7500+i, load the index, then serve.  Every request
+        becomes its own task so that requests arriving together meet in the batcher (one scan for the window)."""
         import asyncio
         import zmq
         import zmq.asyncio
-        ctx = zmq.asyncio.Context()
+        self.context = zmq.asyncio.Context()
         self.running = True
-        receiver = ctx.socket(zmq.PULL)
-        receiver.bind(f"tcp://*:{self.recv_port}")
-        sender = ctx.socket(zmq.PUSH)
-        sender.connect(f"tcp://localhost:{self.send_port}")
-        if not self.simulate and self.faiss_indexes is None:
-            self.load_faiss_index()
-
-        async def reply(query_data):
-            try:
-                await sender.send_json(await self.handle_query(query_data))
-            except Exception as e:  # logged and dropped, as data_source.py:137-138
-                logger.error(f"Error when fetching documents from data source {self.name} (query data: {query_data}): {e}")
+        self.receiver = self.context.socket(zmq.PULL)
+        self.receiver.bind(f"tcp://*:{self.recv_port}")
+        self.sender = self.context.socket(zmq.PUSH)
+        self.sender.connect(f"tcp://localhost:{self.send_port}")
+        self._serve_task = asyncio.current_task()
+        pending = set()
         try:
+            if not self.simulate and self.faiss_indexes is None:
+                self.load_faiss_index()
+
+            async def reply(query_data):
+                try:
+                    await self.sender.send_json(await self.handle_query(query_data))
+                except asyncio.CancelledError:
+                    raise
+                except Exception as e:  # logged, reply dropped — as data_source.py:137-138
+                    logger.error(f"Error when fetching documents from data source {self.name} (query data: {query_data}): {e}")
+
             while self.running:
-                asyncio.ensure_future(reply(await receiver.recv_json()))
+                query_data = await self.receiver.recv_json()
+                task = asyncio.ensure_future(reply(query_data))
+                pending.add(task)
+                task.add_done_callback(pending.discard)
+        except asyncio.CancelledError:
+            logger.info(f"Client {self.client_id} shutdown requested")
         finally:
-            receiver.close()
-            sender.close()
-            ctx.term()
+            for task in list(pending):
+                task.cancel()
+            self.stop()
 
     def stop(self):
+        """Stop serving and close the sockets (data_source.py:217-222)."""
         self.running = False
+        task, self._serve_task = getattr(self, "_serve_task", None), None
+        for name in ("receiver", "sender"):
+            sock = getattr(self, name, None)
+            if sock is not None:
+                sock.close()
+                setattr(self, name, None)
+        ctx = getattr(self, "context", None)
+        if ctx is not None:
+            ctx.term()
+            self.context = None
+        if task is not None and not task.done():
+            import asyncio
+            try:
+                current = asyncio.current_task()
+            except RuntimeError:
+                current = None
+            if task is not current:
+                task.cancel()
+
+
+CURRENT = {}   # client_id -> the DataSource this process serves with (set by run_data_source; introspection / tests)
 
 
 async def run_data_source(client_id: int, dataset: str, name: str, simulate: bool = False):
     """Process entry with the reference's signature (data_source.py:224-226)."""
-    data_source = DataSource(client_id, dataset, name, simulate=simulate)
+    CURRENT[client_id] = data_source = DataSource(client_id, dataset, name, simulate=simulate)
     await data_source.start()

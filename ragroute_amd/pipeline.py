@@ -3,24 +3,31 @@ without the JSON float-list hops of the reference (router.py:317-319 -> http_ser
 
     queries f32 [B, d] on device
       -> router MLP (K3)                   mask [B, C]
-      -> per local shard: convert (K0) + scan/top-k (K1/K2) with the mask column folded in
-      -> [N>1] RCCL all_gather of candidates
+      -> per local shard: convert (K0) + scan/top-k (K1/K2) with the mask column folded in,
+         results written straight into this rank's packed candidate buffer (one slot per local shard)
+      -> [N>1] ONE RCCL all_gather of the packed buffer
       -> merge (K4)                        D f32 [B, k], I i64 [B, k] (global ids: shard << 40 | row)
-Everything is enqueued on the current stream; nothing synchronises with the host."""
-import torch
+Everything is enqueued on the current stream; nothing synchronises with the host.
 
+The reference's counterpart is the fan-out / gather / concat / rerank of http_server.py:198-209, 227-257, 280-293: one
+message per selected source, replies collected in arrival order, flat candidate lists merged by score."""
 from .rerank import merge_topk
-from .sharded import SHARD_SHIFT, alloc_packed, gather_candidates, gather_packed
+from .sharded import SHARD_SHIFT, alloc_packed, gather_packed, max_over_ranks
 
 
 class RetrievalPipeline:
-    def __init__(self, shards, shard_ids, router=None, group=None):
-        """shards: FlatIndex objects local to this rank; shard_ids: their global source ids (columns of the router mask);
-        router: FoldedRouter (or None = routing strategy "all")."""
+    def __init__(self, shards, shard_ids, router=None, group=None, slots=None):
+        """shards: FlatIndex objects local to this rank (any mix of widths: FeB4RAG's sources are 768 / 1024 / 4096 wide,
+        config.py:45-57); shard_ids: their global source ids (columns of the router mask); router: FoldedRouter (or None =
+        routing strategy "all"); slots: candidate slots per rank in the exchange = the largest local shard count over the
+        ranks (default: agreed on by one all_reduce at the first search)."""
+        if len(shards) != len(shard_ids):
+            raise ValueError("one shard id per shard")
         self.shards = list(shards)
         self.shard_ids = [int(s) for s in shard_ids]
         self.router = router
         self.group = group
+        self.slots = slots
         self._packed = {}
 
     def route(self, xq_models):
@@ -29,42 +36,36 @@ class RetrievalPipeline:
             return None, None
         return self.router.run(xq_models)
 
+    def _buffers(self, B, k, device):
+        if self.slots is None:
+            self.slots = max(1, max_over_ranks(len(self.shards), device, self.group))
+        if len(self.shards) > self.slots:
+            raise ValueError(f"{len(self.shards)} local shards but only {self.slots} exchange slots")
+        key = (B, k)
+        if key not in self._packed:
+            buf, D, I = alloc_packed(B, k, device, self.slots)
+            if self.slots == 1:
+                D, I = D[None], I[None]
+            self._packed = {key: (buf, D, I)}
+        return self._packed[key]
+
     def search(self, xq, k, xq_models=None):
         """xq: f32 CUDA [B, d] query embeddings for the shards, or a dict {shard_id: [B, d_shard]} when sources use
-        different encoders (FeB4RAG: 768 / 1024 / 4096 wide, config.py:44-58, http_server.py:201-209 picks the embedding of
-        each source's model); xq_models: router input [B, n_models, d_max] (defaults to xq as the single model)."""
-        if isinstance(xq, dict):
-            return self._search_per_shard(xq, k, xq_models)
-        _, mask = self.route(xq[:, None, :].contiguous() if xq_models is None else xq_models)
-        B = xq.shape[0]
-        if len(self.shards) == 1:
-            # one shard per rank (the benchmark layout): results land in a packed buffer, ONE collective moves it
-            key = (B, k)
-            if key not in self._packed:
-                self._packed = {key: alloc_packed(B, k, xq.device)}
-            buf, D, I = self._packed[key]
-            idx, sid = self.shards[0], self.shard_ids[0]
-            idx.search_prepared(idx.prepare_queries(xq), k, id_offset=sid << SHARD_SHIFT, out=(D, I),
+        different encoders (FeB4RAG: http_server.py:201-209 picks the embedding of each source's model);
+        xq_models: router input [B, n_models, d_max] (defaults to xq as the single model; required for routing when xq is a
+        dict).  Returns (D f32 [B,k], I i64 [B,k]) on device, best first, ids = shard << 40 | row."""
+        per_shard = isinstance(xq, dict)
+        if per_shard:
+            _, mask = (None, None) if xq_models is None else self.route(xq_models)
+            first = next(iter(xq.values()))
+        else:
+            _, mask = self.route(xq[:, None, :].contiguous() if xq_models is None else xq_models)
+            first = xq
+        B = first.shape[0]
+        buf, D, I = self._buffers(B, k, first.device)
+        for slot, (idx, sid) in enumerate(zip(self.shards, self.shard_ids)):
+            q = xq[sid] if per_shard else xq
+            idx.search_prepared(idx.prepare_queries(q), k, id_offset=sid << SHARD_SHIFT, out=(D[slot], I[slot]),
                                 route_mask=None if mask is None else mask[:, sid])
-            Dg, Ig = gather_packed(buf, B, k, self.group)
-            return merge_topk(Dg, Ig, k, True)
-        Ds, Is = [], []
-        for idx, sid in zip(self.shards, self.shard_ids):
-            D, I = idx.search_prepared(idx.prepare_queries(xq), k, id_offset=sid << SHARD_SHIFT,
-                                       route_mask=None if mask is None else mask[:, sid])
-            Ds.append(D)
-            Is.append(I)
-        Dg, Ig = gather_candidates(torch.cat(Ds, 1), torch.cat(Is, 1), self.group)
-        return merge_topk(Dg, Ig, k, True)
-
-    def _search_per_shard(self, xq_by_shard, k, xq_models):
-        _, mask = (None, None) if xq_models is None else self.route(xq_models)
-        Ds, Is = [], []
-        for idx, sid in zip(self.shards, self.shard_ids):
-            xq = xq_by_shard[sid]
-            D, I = idx.search_prepared(idx.prepare_queries(xq), k, id_offset=sid << SHARD_SHIFT,
-                                       route_mask=None if mask is None else mask[:, sid])
-            Ds.append(D)
-            Is.append(I)
-        Dg, Ig = gather_candidates(torch.cat(Ds, 1), torch.cat(Is, 1), self.group)
+        Dg, Ig = gather_packed(buf, B, k, self.group, self.slots)
         return merge_topk(Dg, Ig, k, True)

@@ -11,14 +11,28 @@ import torch
 from ._lib import check, lib
 
 
+MERGE_MAX = 8192   # candidates per query one rr_merge_topk launch sorts in LDS (csrc/rr_common.h kSelectCap)
+
+
 def merge_topk(D, I, k, descending=True):
     """D f32 [nq,m], I i64 [nq,m] CUDA tensors -> (D [nq,k], I [nq,k]) best-first; ties by ascending id;
-    id < 0 marks padding.  Enqueued on the current stream."""
+    id < 0 marks padding.  Enqueued on the current stream.
+
+    Contract beyond the reference's one-query list merge (rerank.py:3-9, 28-34):
+      * NaN-scored candidates are dropped (treated as padding).  The scan kernels never emit one (a NaN score is never
+        selected), so after the candidate exchange there is nothing to drop; the list-shaped `rerank_medrag` /
+        `rerank_wikipedia` below restore numpy's placement of NaNs on the host.
+      * m > 8192 is merged in rounds (per-slice top-k, then a merge of the survivors), which needs k <= 4096."""
     if D.shape != I.shape or D.dim() != 2:
         raise ValueError("merge_topk needs D and I of the same [nq,m] shape")
     D = D.to(torch.float32).contiguous()
     I = I.to(torch.int64).contiguous()
     nq, m = D.shape
+    if m > MERGE_MAX:
+        if k > MERGE_MAX // 2:
+            raise ValueError(f"merge_topk: {m} candidates per query need k <= {MERGE_MAX // 2}, got k={k}")
+        parts = [merge_topk(D[:, s:s + MERGE_MAX], I[:, s:s + MERGE_MAX], k, descending) for s in range(0, m, MERGE_MAX)]
+        return merge_topk(torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 1), k, descending)
     Do = torch.empty((nq, k), dtype=torch.float32, device=D.device)
     Io = torch.empty((nq, k), dtype=torch.int64, device=D.device)
     check(lib().rr_merge_topk(D.data_ptr(), I.data_ptr(), nq, m, k, int(bool(descending)), Do.data_ptr(), Io.data_ptr(),
@@ -27,16 +41,29 @@ def merge_topk(D, I, k, descending=True):
 
 
 def _rerank_by_score(docs, scores, k, descending):
+    """The reference sorts the float64 list with numpy (rerank.py:5, 30).  Here: scores are compared as float32 (what the
+    data sources return: faiss D is f32, data_source.py:187), candidate position is the tie-break (earlier first; numpy's
+    default sort leaves ties unspecified), and NaN scores are placed where numpy's argsort puts them — at the END of the
+    ascending order: `[::-1]` therefore ranks them FIRST for rerank_medrag, rerank_wikipedia keeps them last."""
     n = len(scores)
     if n == 0:
         return [], []
     if len(docs) != n:
         raise ValueError("docs and scores must have the same length")
-    D = torch.tensor(np.asarray(scores, np.float64).astype(np.float32)[None, :], device="cuda")
-    I = torch.arange(n, dtype=torch.int64, device="cuda")[None, :]
-    _, order = merge_topk(D, I, min(k, n), descending)
-    order = order[0].cpu().tolist()
-    order = [i for i in order if i >= 0]
+    if k <= 0:
+        return [], []
+    s32 = np.asarray(scores, np.float64).astype(np.float32)
+    nan_pos = np.flatnonzero(np.isnan(s32))
+    head = [int(i) for i in nan_pos[::-1][:k]] if descending else []      # reversed tail of the ascending order
+    want = min(k, n) - len(head)
+    order = []
+    if want > 0 and n - len(nan_pos) > 0:
+        D = torch.from_numpy(s32[None, :]).to("cuda")
+        I = torch.arange(n, dtype=torch.int64, device="cuda")[None, :]
+        _, o = merge_topk(D, I, want, descending)
+        order = [i for i in o[0].cpu().tolist() if i >= 0]
+    tail = [] if descending else [int(i) for i in nan_pos[: max(0, min(k, n) - len(order))]]
+    order = head + order + tail
     return [docs[i] for i in order], [scores[i] for i in order]
 
 

@@ -180,6 +180,9 @@ class Router:
         self.scaler = None
         self.centroids: Dict[str, np.ndarray] = {}
         self._folded: Optional[FoldedRouter] = None
+        self._batcher = None
+        self._serve_task = None
+        self.batch_window_ms = float(os.environ.get("RAGROUTE_BATCH_WINDOW_MS", 2.0))
 
     # -- loading (router.py:106-151) -------------------------------------------------------------
     def load_router(self, model_path=None, scaler_path=None, stats_files=None):
@@ -293,36 +296,110 @@ class Router:
             raise NotImplementedError("query encoders are outside the hot path; pass encoder= or use simulate=True")
         return self.encoder(query)
 
+    # -- batched serving -------------------------------------------------------------
+    def route_window(self, embeddings_list):
+        """ONE fused-kernel launch for a window of requests: list of {model: embedding} -> list of source-name lists
+        (what select_relevant_sources_ragroute returns for each of them on its own, router.py:241-283)."""
+        d_max = config.EMBEDDING_MAX_LENGTH[self.dataset]
+        x = np.zeros((len(embeddings_list), len(self.model_names), d_max), np.float32)
+        for b, emb in enumerate(embeddings_list):
+            for m, name in enumerate(self.model_names):
+                e = np.asarray(emb[name], np.float32).reshape(-1)
+                x[b, m, : e.shape[0]] = e
+        _, mask = self.route_batch(torch.from_numpy(x))
+        keep = mask.cpu().numpy()
+        return [[c for p, c in zip(row, self.data_sources) if p] for row in keep]
+
+    async def handle_query(self, query_data):
+        """Reply message for one request, in the reference's wire format (router.py:305-332).  With the `ragroute`
+        strategy concurrent requests are coalesced by the batcher into one router-MLP launch of up to 256 queries; the
+        reference serves them strictly one at a time (router.py:207-219)."""
+        import asyncio
+        start_time = time.time()
+        query_embeddings = self.encode_query(query_data["query"])
+        embed_time = time.time() - start_time
+        start_time = time.time()
+        if self.simulate or self.routing_strategy != "ragroute":
+            sources_corpora = self.select_relevant_sources(query_embeddings)
+        else:
+            if self._batcher is None:
+                from .queue_manager import QueryBatcher
+                self._batcher = QueryBatcher(self.route_window, max_batch=256, max_wait_ms=self.batch_window_ms)
+            sources_corpora = await self._batcher.submit(query_embeddings)
+        select_time = time.time() - start_time
+        serialized = {m: (e.tolist() if isinstance(e, np.ndarray) else e) for m, e in query_embeddings.items()}
+        if self.simulate:
+            await asyncio.sleep(config.ROUTER_DELAY)  # router.py:321-322
+        return {"query_id": query_data["id"], "data_sources": sources_corpora, "embeddings": serialized,
+                "embedding_time": embed_time, "selection_time": select_time}
+
     # -- service loop (transport glue; needs pyzmq, which the reference also needs) -----------------
-    async def start(self):  # pragma: no cover - needs pyzmq
+    async def start(self):
+        """router.py:153-219: bind PULL :5555, connect PUSH :5556, load the weights, then serve.  Every request becomes its
+        own task so that requests arriving together meet in the batcher."""
+        import asyncio
         import zmq
         import zmq.asyncio
-        ctx = zmq.asyncio.Context()
+        self.context = zmq.asyncio.Context()
         self.running = True
-        recv = ctx.socket(zmq.PULL)
-        recv.bind(f"tcp://*:{config.SERVER_ROUTER_PORT}")
-        send = ctx.socket(zmq.PUSH)
-        send.connect(f"tcp://localhost:{config.ROUTER_SERVER_PORT}")
-        if not self.simulate and self._folded is None:
-            self.load_router()
+        self.receiver = self.context.socket(zmq.PULL)
+        self.receiver.bind(f"tcp://*:{config.SERVER_ROUTER_PORT}")
+        self.sender = self.context.socket(zmq.PUSH)
+        self.sender.connect(f"tcp://localhost:{config.ROUTER_SERVER_PORT}")
+        self._serve_task = asyncio.current_task()
+        pending, failure = set(), []
         try:
+            if not self.simulate:
+                if self.router is None:  # weights installed through set_router() are kept
+                    self.load_router()
+                if self.routing_strategy == "ragroute":  # warm-up forward, as router.py:173-175
+                    self.route_batch(torch.zeros((1, len(self.model_names), config.EMBEDDING_MAX_LENGTH[self.dataset])))
+
+            async def reply(query_data):
+                await self.sender.send_json(await self.handle_query(query_data))
+
+            def done(task):  # the reference lets a failing query end the router (router.py:213, no try/except): so do we
+                pending.discard(task)
+                if not task.cancelled() and task.exception() is not None and not failure:
+                    failure.append(task.exception())
+                    if self._serve_task is not None:
+                        self._serve_task.cancel()
+
             while self.running:
-                q = await recv.recv_json()
-                t0 = time.time()
-                emb = self.encode_query(q["query"])
-                t1 = time.time()
-                srcs = self.select_relevant_sources(emb)
-                t2 = time.time()
-                await send.send_json({"query_id": q["id"], "data_sources": srcs,
-                                      "embeddings": {m: (e.tolist() if isinstance(e, np.ndarray) else e) for m, e in emb.items()},
-                                      "embedding_time": t1 - t0, "selection_time": t2 - t1})
+                query_data = await self.receiver.recv_json()
+                task = asyncio.ensure_future(reply(query_data))
+                pending.add(task)
+                task.add_done_callback(done)
+        except asyncio.CancelledError:
+            logger.info("Router shutdown requested")
         finally:
-            recv.close()
-            send.close()
-            ctx.term()
+            for task in list(pending):
+                task.cancel()
+            self.stop()
+        if failure:
+            raise failure[0]
 
     def stop(self):
+        """router.py:335-341: stop serving, close both sockets, terminate the context."""
         self.running = False
+        task, self._serve_task = self._serve_task, None
+        for name in ("receiver", "sender"):
+            sock = getattr(self, name, None)
+            if sock is not None:
+                sock.close()
+                setattr(self, name, None)
+        ctx = getattr(self, "context", None)
+        if ctx is not None:
+            ctx.term()
+            self.context = None
+        if task is not None and not task.done():
+            import asyncio
+            try:
+                current = asyncio.current_task()
+            except RuntimeError:
+                current = None
+            if task is not current:
+                task.cancel()  # the loop is parked in recv_json: wake it so it can leave
 
 
 class _ScalerLike:
@@ -331,7 +408,21 @@ class _ScalerLike:
         self.scale_ = np.asarray(scale, np.float64)
 
 
+_ENCODER_FACTORY = None
+CURRENT = None   # the Router this process serves with (set by run_router; introspection / tests)
+
+
+def set_encoder_factory(factory):
+    """Plug the query encoders in: factory(dataset) -> callable(str) -> {model_name: np.ndarray}.  The encoders themselves
+    (router.py:85-104, 285-303: MedCPT, DPR, the FeB4RAG zoo) are outside the hot path; `run_router` keeps the reference's
+    signature, so this module-level hook is how a deployment (or a test) supplies them."""
+    global _ENCODER_FACTORY
+    _ENCODER_FACTORY = factory
+
+
 async def run_router(dataset: str, data_sources: List[str], routing_strategy: str, simulate: bool = False):
     """Process entry with the reference's signature (router.py:343-346)."""
-    router = Router(dataset, data_sources, routing_strategy, simulate=simulate)
+    encoder = _ENCODER_FACTORY(dataset) if (_ENCODER_FACTORY is not None and not simulate) else None
+    global CURRENT
+    CURRENT = router = Router(dataset, data_sources, routing_strategy, simulate=simulate, encoder=encoder)
     await router.start()

@@ -48,63 +48,87 @@ def gather_candidates(D, I, group=None):
             Ig.view(world, B, k).permute(1, 0, 2).reshape(B, world * k))
 
 
-def alloc_packed(B, k, device):
-    """One allocation holding D f32[B,k] followed by I i64[B,k]: the kernels write straight into the two views and the
-    exchange moves the whole buffer with ONE collective."""
-    nD = B * k * 4
+def alloc_packed(B, k, device, slots=1):
+    """One allocation holding D f32[slots,B,k] followed by I i64[slots,B,k] (one slot per local shard): the scan kernels
+    write straight into the views and the exchange moves the whole buffer with ONE collective.  Every slot starts as
+    padding (-inf, -1), so a rank with fewer shards than `slots` contributes nothing for the unused ones.
+    Returns (buf, D, I); with slots == 1 the views are [B,k]."""
+    nD = slots * B * k * 4
     pad = (-nD) % 8
-    buf = torch.empty(nD + pad + B * k * 8, dtype=torch.uint8, device=device)
-    D = buf[:nD].view(torch.float32).view(B, k)
-    I = buf[nD + pad:].view(torch.int64).view(B, k)
-    return buf, D, I
+    buf = torch.empty(nD + pad + slots * B * k * 8, dtype=torch.uint8, device=device)
+    D = buf[:nD].view(torch.float32).view(slots, B, k)
+    I = buf[nD + pad:].view(torch.int64).view(slots, B, k)
+    D.fill_(float("-inf"))
+    I.fill_(-1)
+    return (buf, D[0], I[0]) if slots == 1 else (buf, D, I)
 
 
-def gather_packed(buf, B, k, group=None):
-    """all_gather of packed candidate buffers (see alloc_packed) -> ([B, G*k] scores, [B, G*k] ids), rank-major columns."""
+def gather_packed(buf, B, k, group=None, slots=1):
+    """all_gather of packed candidate buffers (see alloc_packed) -> ([B, G*slots*k] scores, [B, G*slots*k] ids); columns are
+    rank-major, then slot-major: rank r's shard slot s occupies columns (r*slots + s)*k .. +k."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    nD = B * k * 4
+    nD = slots * B * k * 4
     pad = (-nD) % 8
     if world == 1:
-        return buf[:nD].view(torch.float32).view(B, k), buf[nD + pad:].view(torch.int64).view(B, k)
-    if buf.is_cuda and dist.get_backend(group) == "gloo":  # rehearsal on one box: stage through the host
+        out = buf.view(1, buf.numel())
+    elif buf.is_cuda and dist.get_backend(group) == "gloo":  # rehearsal on one box: stage through the host
         out = torch.empty(world * buf.numel(), dtype=torch.uint8)
         dist.all_gather_into_tensor(out, buf.cpu(), group=group)
-        out = out.to(buf.device)
+        out = out.to(buf.device).view(world, buf.numel())
     else:
         out = torch.empty(world * buf.numel(), dtype=torch.uint8, device=buf.device)
         dist.all_gather_into_tensor(out, buf, group=group)
-    out = out.view(world, buf.numel())
-    Dg = out[:, :nD].contiguous().view(torch.float32).view(world, B, k).permute(1, 0, 2).reshape(B, world * k)
-    Ig = out[:, nD + pad:].contiguous().view(torch.int64).view(world, B, k).permute(1, 0, 2).reshape(B, world * k)
+        out = out.view(world, buf.numel())
+    if world == 1 and slots == 1:
+        return out[0, :nD].view(torch.float32).view(B, k), out[0, nD + pad:].view(torch.int64).view(B, k)
+    Dg = out[:, :nD].contiguous().view(torch.float32).view(world * slots, B, k).permute(1, 0, 2).reshape(B, world * slots * k)
+    Ig = out[:, nD + pad:].contiguous().view(torch.int64).view(world * slots, B, k).permute(1, 0, 2).reshape(B, world * slots * k)
     return Dg, Ig
 
 
-class ShardedFlatSearch:
-    """This rank's shards (FlatIndex objects) + the exchange/merge step."""
+def max_over_ranks(value, device, group=None):
+    """max of a small integer over the ranks (used once, to size the packed buffer to the largest local shard count)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return int(value)
+    on_dev = dist.get_backend(group) != "gloo"
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device if on_dev else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
 
-    def __init__(self, shards, shard_ids, group=None):
+
+class ShardedFlatSearch:
+    """This rank's shards (FlatIndex objects) + the exchange/merge step, for queries already in the scan format
+    (all shards of one width).  RetrievalPipeline is the general form (router, per-shard encoders)."""
+
+    def __init__(self, shards, shard_ids, group=None, slots=None):
         if len(shards) != len(shard_ids):
             raise ValueError("one shard id per shard")
         self.shards = list(shards)
         self.shard_ids = [int(s) for s in shard_ids]
         self.group = group
+        self.slots = slots
+        self._packed = {}
 
     def local_candidates(self, xq_half, k, route_mask=None):
-        """Scan every local shard; returns [B, S_local*k] candidates with global ids.
+        """Scan every local shard into this rank's packed buffer; returns (buf, D [slots,B,k], I [slots,B,k]) with global ids.
         route_mask: optional bool [B, n_total_shards] (router output)."""
-        Ds, Is = [], []
-        for idx, sid in zip(self.shards, self.shard_ids):
-            D, I = idx.search_prepared(xq_half, k, id_offset=sid << SHARD_SHIFT,
-                                       route_mask=None if route_mask is None else route_mask[:, sid])
-            Ds.append(D)
-            Is.append(I)
-        return (Ds[0], Is[0]) if len(Ds) == 1 else (torch.cat(Ds, 1), torch.cat(Is, 1))
+        B = xq_half.shape[0]
+        if self.slots is None:
+            self.slots = max(1, max_over_ranks(len(self.shards), xq_half.device, self.group))
+        if (B, k) not in self._packed:
+            buf, D, I = alloc_packed(B, k, xq_half.device, self.slots)
+            self._packed = {(B, k): (buf, D[None], I[None]) if self.slots == 1 else (buf, D, I)}
+        buf, D, I = self._packed[(B, k)]
+        for slot, (idx, sid) in enumerate(zip(self.shards, self.shard_ids)):
+            idx.search_prepared(xq_half, k, id_offset=sid << SHARD_SHIFT, out=(D[slot], I[slot]),
+                                route_mask=None if route_mask is None else route_mask[:, sid])
+        return buf, D, I
 
     def search(self, xq_half, k, route_mask=None):
-        """Full federated step on device: local scans -> all_gather -> merge.  Every rank gets the result."""
+        """Full federated step on device: local scans -> ONE all_gather -> merge.  Every rank gets the result."""
         from .rerank import merge_topk
-        D, I = self.local_candidates(xq_half, k, route_mask)
-        Dg, Ig = gather_candidates(D, I, self.group)
+        buf, _, _ = self.local_candidates(xq_half, k, route_mask)
+        Dg, Ig = gather_packed(buf, xq_half.shape[0], k, self.group, self.slots)
         if Dg.shape[1] == k and route_mask is None:
             return Dg, Ig
         return merge_topk(Dg, Ig, k, True)

@@ -317,3 +317,56 @@ def test_torch_router_op_equals_router_class(gpu):
     l2, m2 = torch.ops.ragroute.router_mlp(xq, t["w1q"], t["c1"], t["ln1_g"], t["ln1_b"], t["w2"], t["b2"], t["ln2_g"], t["ln2_b"], t["w3"],
                                            t["model_of_source"], float(np.asarray(sd["fc3.bias"]).reshape(-1)[0]), r._folded.struct.prob_threshold)
     assert torch.equal(l2, logits) and torch.equal(m2, mask)
+
+
+def test_rerank_nan_and_long_lists_follow_numpy(gpu):
+    """rerank.py:5 is `np.argsort(scores)[::-1][:k]`, rerank.py:30 `np.argsort(scores)[:k]`: numpy sorts NaN to the END of the
+    ascending order, so rerank_medrag ranks a NaN-scored document FIRST and rerank_wikipedia keeps it last.  Also lists longer
+    than one device merge (8192 candidates), which the reference handles like any other length."""
+    from ragroute_amd.rerank import rerank_medrag, rerank_wikipedia
+    rng = np.random.default_rng(12)
+    scores = rng.permutation(40).astype(np.float64).tolist()       # tie-free
+    scores[17] = float("nan")
+    docs = [f"d{i}" for i in range(40)]
+    for k in (1, 5, 39, 40, 64):
+        order = np.argsort(scores)[::-1][:k]
+        d, s = rerank_medrag(docs, scores, k)
+        assert d == [docs[i] for i in order]
+        assert [x for x in s if x == x] == [scores[i] for i in order if scores[i] == scores[i]] and (s[0] != s[0])
+        order = np.argsort(scores)[:k]
+        d, s = rerank_wikipedia(docs, scores, k)
+        assert d == [docs[i] for i in order]
+    n = 20_000                                                     # > 8192 candidates: merged in rounds
+    scores = rng.permutation(n).astype(np.float64).tolist()
+    docs = list(range(n))
+    d, s = rerank_medrag(docs, scores, 32)
+    order = np.argsort(scores)[::-1][:32]
+    assert d == order.tolist() and s == [scores[i] for i in order]
+    d, s = rerank_wikipedia(docs, scores, 100)
+    assert d == np.argsort(scores)[:100].tolist()
+
+
+def test_data_source_serves_an_l2_index_wider_than_768(gpu, tmp_path, monkeypatch):
+    """An IxF2 file decides the metric (faiss.read_index, data_source.py:71); L2 works at every width (here FeB4RAG's 1024)."""
+    from oracle import oracle as O
+    from ragroute_amd import config as C
+    from ragroute_amd import data_source as DS
+    monkeypatch.setattr(C, "FEB4RAG_DIR", str(tmp_path))
+    rng = np.random.default_rng(4)
+    xb = int_data(rng, 9000, 1024)
+    ds = DS.DataSource(0, "feb4rag", "msmarco")     # e5-large: 1024 wide (config.py:45)
+    os.makedirs(ds.index_dir)
+    DS.write_faiss_flat_index(ds.index_path, xb, metric="l2")
+    docids = [f"m{i}" for i in range(len(xb))]
+    json.dump(docids, open(ds.doc_ids_path, "w"))
+    cdir = tmp_path / "dataset_creation/original_dataset" / "msmarco" / "msmarco"
+    os.makedirs(cdir)
+    open(cdir / "corpus.jsonl", "w").write("\n".join(json.dumps({"_id": d, "text": d}) for d in docids))
+    ds.load_faiss_index()
+    assert ds.index_metric == "l2" and ds.faiss_indexes[0].metric == "l2" and ds.faiss_indexes[0].d == 1024
+    xq = int_data(rng, 5, 1024)
+    Dr, Ir = O.flat_search_l2(xb, xq, 10)
+    D, I = ds.faiss_indexes[0].search(xq, 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    ids, docs, scores = ds.retrieve_docs_fed4rag(xq[:1], 10)
+    assert ids == [docids[i] for i in Ir[0]] and scores == []

@@ -62,3 +62,89 @@ def test_two_rank_candidate_exchange(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+# ---- BASELINE config 4's layout: several shards of different widths per rank + route mask + ONE exchange ------------
+class _OracleIndex:
+    """Test double with FlatIndex's device-to-device interface (prepare_queries / search_prepared), backed by the oracle:
+    the HIP scan needs a GPU, the orchestration under test (RetrievalPipeline + the packed exchange) does not."""
+
+    def __init__(self, xb):
+        self.xb, self.d = xb, xb.shape[1]
+
+    def prepare_queries(self, xq):
+        assert xq.shape[1] == self.d
+        return xq
+
+    def search_prepared(self, xq, k, id_offset=0, out=None, route_mask=None):
+        from oracle import oracle as O
+        D, I = O.flat_search_ip(self.xb, xq.numpy(), k)
+        I = np.where(I >= 0, I + id_offset, -1)
+        if route_mask is not None:
+            keep = route_mask.numpy().astype(bool)[:, None]
+            D, I = np.where(keep, D, -np.inf).astype(np.float32), np.where(keep, I, -1)
+        out[0].copy_(torch.from_numpy(D))
+        out[1].copy_(torch.from_numpy(I))
+        return out
+
+
+class _FixedRouter:
+    def __init__(self, mask):
+        self.mask = mask
+
+    def run(self, xq_models):
+        return None, self.mask
+
+
+def _config4_worker(rank, world, port, out_dir, layout):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from ragroute_amd import pipeline as P
+        from ragroute_amd.sharded import SHARD_SHIFT
+        from tests.util import int_data
+        # the device merge needs a GPU: stand it in with the oracle's merge (same contract), the exchange layout is what is checked
+        P.merge_topk = lambda D, I, k, desc: tuple(torch.from_numpy(a) for a in O.merge_topk(D.numpy(), I.numpy(), k, desc))
+        rng = np.random.default_rng(7)  # same stream on both ranks
+        widths = {0: 768, 1: 1024, 2: 4096, 3: 768}            # FeB4RAG-shaped: config.py:45-57, 92-96
+        rows = {0: 500, 1: 333, 2: 260, 3: 41}
+        shards = {s: int_data(rng, rows[s], widths[s]) for s in widths}
+        nq, k = 7, 10                                           # K["feb4rag"] = 10 (config.py:99)
+        xq = {s: int_data(rng, nq, widths[s]) for s in widths}  # one embedding per source's encoder (http_server.py:201-209)
+        mask = torch.from_numpy(rng.integers(0, 2, size=(nq, 4)).astype(bool))
+        mask[0] = False                                         # a query routed nowhere
+        mask[1] = True
+        mine = layout[rank]
+        pipe = P.RetrievalPipeline([_OracleIndex(shards[s]) for s in mine], mine, router=_FixedRouter(mask))
+        D, I = pipe.search({s: torch.from_numpy(xq[s]) for s in mine}, k, xq_models=torch.zeros(nq, 1, 1))
+        assert pipe.slots == max(len(l) for l in layout)
+        D, I = D.numpy(), I.numpy()
+        for q in range(nq):
+            # expectation: the reference's flow — each selected source answers with its own top-k (data_source.py:158-163),
+            # the front-end concatenates and keeps the k best (http_server.py:280-293, rerank.py:3-9)
+            cand = []
+            for s in range(4):
+                if mask[q, s]:
+                    Ds, Is = O.flat_search_ip(shards[s], xq[s][q:q + 1], k)
+                    cand += [(-float(d), (s << SHARD_SHIFT) + int(i)) for d, i in zip(Ds[0], Is[0]) if i >= 0]
+            cand.sort()
+            want_I = [i for _, i in cand[:k]] + [-1] * (k - len(cand[:k]))
+            want_D = [-d for d, _ in cand[:k]] + [-np.inf] * (k - len(cand[:k]))
+            assert I[q].tolist() == want_I, (q, I[q].tolist(), want_I)
+            assert D[q].tolist() == want_D
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_two_shards_each_mixed_widths_route_mask(tmp_path):
+    """World 2, each rank holding two sources of different widths, router mask, per-source embeddings."""
+    mp.spawn(_config4_worker, args=(2, _free_port(), str(tmp_path), [[0, 2], [1, 3]]), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+def test_two_ranks_uneven_shard_counts(tmp_path):
+    """13 sources over 8 GPUs leaves ranks with different shard counts: the unused exchange slot stays padding."""
+    mp.spawn(_config4_worker, args=(2, _free_port(), str(tmp_path), [[0, 1, 2], [3]]), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
