@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 
 #include "rr_common.h"
 #include "rr_kernels.h"
@@ -53,7 +54,7 @@ hipError_t profiled_scan(const rr::ScanArgs& a, int dtype, int D, bool dense, in
 }
 
 // Schedule knobs (defaults from rr_common.h; RR_SAMPLE_ROWS / RR_CHUNK_GROWTH override them for tuning runs)
-int g_sample_rows = rr::kSampleRows, g_chunk_growth = rr::kChunkGrowth;
+int g_sample_rows = rr::kSampleRows, g_chunk_growth = 0;  // 0 = size-aware schedule
 void read_schedule_env() {
   static const bool once = [] {
     if (const char* v = getenv("RR_SAMPLE_ROWS")) {
@@ -71,6 +72,24 @@ void read_schedule_env() {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Growth factor of the chunk schedule for a shard that is `ratio` times the bootstrap sample.  With c chunks the growth is
+// g = ratio^(1/c) and every chunk leaves ~(g - 1) k survivors per query.  A workgroup sees every query, so it takes the
+// insertion path ~(g - 1) k times per chunk, and its four waves wait for each other at the next tile barrier.  Cost model
+// (MI355X, measured in round 2: a 2-chunk schedule at 10M rows ran 0.16 ms SLOWER than the 4-chunk one): ~37 us per chunk
+// for the launch's fixed part and its compaction, ~0.18 us per insertion event of a workgroup.
+// 1M x 768, k = 32 -> 3 chunks; 10M -> 4; 80M at k = 100 -> 6.
+double chunk_schedule(double ratio, int k) {
+  if (g_chunk_growth > 0) return (double)g_chunk_growth;   // RR_CHUNK_GROWTH pins the round-1 schedule for A/B runs
+  if (ratio <= 1.0) return 2.0;
+  double best_cost = 1e30, best_g = 8.0;
+  for (int c = 1; c <= 8; ++c) {
+    const double g = pow(ratio, 1.0 / c);
+    const double cost = c * (37.0 + 0.18 * (g - 1.0) * k);
+    if (cost < best_cost) { best_cost = cost; best_g = g; }
+  }
+  return best_g < 1.5 ? 1.5 : best_g;
+}
+
 struct Workspace {
   float* thr;
   uint32_t* list_cnt;
@@ -79,6 +98,7 @@ struct Workspace {
   uint64_t* scratch;
   float* dense;
   uint64_t* cand;
+  void* xqs;
   size_t total;
 };
 
@@ -95,6 +115,7 @@ Workspace carve(char* base, int k, int grid) {
   w.scratch = (uint64_t*)take((size_t)grid * 8 * cap * sizeof(uint64_t));  // up to 2 workgroups per CU x 4 waves
   w.dense = (float*)take((size_t)kQueriesPerBlock * kSampleRows * sizeof(float));
   w.cand = (uint64_t*)take((size_t)kQueriesPerBlock * grid * 4 * cap * sizeof(uint64_t));
+  w.xqs = take((size_t)kQueriesPerBlock * kMaxResidentDim * 2);  // the query block in MFMA-fragment order (prep kernel)
   w.total = off;
   return w;
 }
@@ -103,7 +124,7 @@ Workspace carve(char* base, int k, int grid) {
 
 extern "C" {
 
-int rr_version(void) { return 200; }  // 0.2.0: screened search, wide rows, L2 for every dimension
+int rr_version(void) { return 300; }  // 0.3.0: prep kernel (fragment-order queries), fused finalize, deeper wide-row pipeline, size-aware chunk schedule
 const char* rr_last_error(void) { return g_err; }
 int rr_device_cus(void) {
   int v = device_cus();
@@ -186,8 +207,10 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
     a.xb = xb; a.xq = xq_b; a.thr = w.thr; a.cand = w.cand; a.cand_cnt = w.cand_cnt; a.scratch = w.scratch;
     a.dense = w.dense; a.n_rows = (uint32_t)n_rows; a.nq = (uint32_t)nqb; a.dense_ld = kSampleRows; a.cap = cap; a.k = k;
     a.half_sqnorm = half_sqnorm;
+    a.xqs = w.xqs;
 
-    RR_CHECK(launch_init_state(s, st), "rr_flat_search/init");
+    bool finalized = false;
+    RR_CHECK(launch_prep(s, xq_b, w.xqs, dim, st), "rr_flat_search/prep");
     if (n_rows > 0 && n_rows <= kDenseMaxRows) {
       // tiny corpus: all scores, one exact selection
       a.tile_first = 0; a.tile_stride = 1; a.n_tiles = total_tiles;
@@ -201,21 +224,31 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
       RR_CHECK(profiled_scan(a, dtype, dim, true, grid, st), "rr_flat_search/bootstrap");
       s.tile_first = 0; s.tile_stride = a.tile_stride; s.dense_cols = (uint32_t)g_sample_rows;
       RR_CHECK(launch_dense_select(s, true, st), "rr_flat_search/bootstrap_select");
-      // chunks [0,e1), [e1,e2), ... with e growing 8x: ~7k survivors per query and chunk
-      uint64_t begin = 0, end = (uint64_t)n_sample_tiles * g_chunk_growth;  // in tiles
+      // chunks [0,e1), [e1,e2), ... with e growing geometrically: a chunk that is g times what came before it yields ~(g-1) k
+      // survivors per query.  The number of chunks balances the fixed cost of a scan launch + compaction against the
+      // insertion work of a long chunk (chunk_schedule).
+      const double growth = chunk_schedule((double)total_tiles / n_sample_tiles, k);
+      FinalizeArgs fin{D_b, I_b, id_offset, route_mask ? route_mask + (size_t)qb * mask_stride : nullptr, mask_stride};
+      uint64_t begin = 0;
+      double endf = (double)n_sample_tiles * growth;  // in tiles
       while (begin < total_tiles) {
-        if (end > total_tiles) end = total_tiles;
+        uint64_t end = (uint64_t)(endf + 0.5);
+        if (end > total_tiles || (double)total_tiles < endf * 1.25) end = total_tiles;  // no sliver of a last chunk
+        if (end <= begin) end = begin + 1;
         a.tile_first = (uint32_t)begin; a.tile_stride = 1; a.n_tiles = (uint32_t)(end - begin);
         a.timeline = getenv("RR_SCAN_TIMELINE") ? (uint64_t*)w.dense : nullptr;  // the dense buffer is idle during chunk scans
         RR_CHECK(profiled_scan(a, dtype, dim, false, grid, st), "rr_flat_search/scan");
-        RR_CHECK(launch_compact(s, st), "rr_flat_search/compact");
+        const bool last = end == total_tiles;
+        RR_CHECK(launch_compact(s, (last && !half_sqnorm) ? &fin : nullptr, st), "rr_flat_search/compact");
+        if (last && !half_sqnorm) finalized = true;
         begin = end;
-        end *= g_chunk_growth;
+        endf *= growth;
       }
     }
-    RR_CHECK(launch_finalize(s, D_b, I_b, id_offset, route_mask ? route_mask + (size_t)qb * mask_stride : nullptr, mask_stride,
-                             half_sqnorm ? (const void*)xq_b : nullptr, dtype, dim, st),
-             "rr_flat_search/finalize");
+    if (!finalized)
+      RR_CHECK(launch_finalize(s, D_b, I_b, id_offset, route_mask ? route_mask + (size_t)qb * mask_stride : nullptr, mask_stride,
+                               half_sqnorm ? (const void*)xq_b : nullptr, dtype, dim, st),
+               "rr_flat_search/finalize");
   }
 #undef RR_CHECK
   return RR_OK;

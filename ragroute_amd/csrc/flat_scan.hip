@@ -115,17 +115,17 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
 
   // (the first two tiles are already in flight: their HBM latency overlaps the query loads below)
   // ---- resident queries: B fragment (qb, s2): query wave*64 + qb*16 + col, k = 32 s2 + 8 g .. +7 -------------
+  // (read from the fragment-order copy the prep kernel made, a.xqs: every load is one contiguous KiB per wave)
   frag q[4][KS2];
   {
-    const T* xq = (const T*)a.xq;
+    const T* xqs = (const T*)a.xqs;
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) {
-      const uint32_t qi = wave * 64 + qb * 16 + col;
-      const T* p = xq + (size_t)(qi < a.nq ? qi : a.nq - 1) * D + 8 * g;
+      const T* p = xqs + ((size_t)(wave * 4 + qb) * KS2 * 64 + lane) * 8;
 #pragma unroll
       for (int s2 = 0; s2 < KS2; ++s2) {
-        if (qb * KS2 + s2 < NAQ) agpr_load_frag(q[qb][s2], p + 32 * s2);
-        else q[qb][s2] = *(const frag*)(p + 32 * s2);
+        if (qb * KS2 + s2 < NAQ) agpr_load_frag(q[qb][s2], p + 512 * s2);
+        else q[qb][s2] = *(const frag*)(p + 512 * s2);
       }
     }
 #pragma unroll

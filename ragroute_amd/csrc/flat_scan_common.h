@@ -91,7 +91,7 @@ __device__ __forceinline__ void mfma_drain(f32x16& a0, f32x16& a1) {
 // Wave-cooperative exact compaction of one lane's candidate buffer: keep the k largest keys
 // (sorted, descending) and return the k-th key.  All 64 lanes participate; buf/scratch/cnt are
 // wave-uniform.  Keys are unique (ids are unique), so ranks form a permutation.
-static __device__ __noinline__ uint64_t wave_compact(uint64_t* buf, uint64_t* scratch, int cnt, int k, int lane) {
+static __device__ __forceinline__ uint64_t wave_compact_inl(uint64_t* buf, uint64_t* scratch, int cnt, int k, int lane) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int e0 = 0; e0 < cnt; e0 += 64) {
     const int e = e0 + lane;
@@ -111,6 +111,9 @@ static __device__ __noinline__ uint64_t wave_compact(uint64_t* buf, uint64_t* sc
   const uint64_t kth = scratch[k - 1];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   return kth;
+}
+static __device__ __noinline__ uint64_t wave_compact(uint64_t* buf, uint64_t* scratch, int cnt, int k, int lane) {
+  return wave_compact_inl(buf, scratch, cnt, k, lane);
 }
 
 // max without the canonicalising v_max(x,x) hipcc puts in front of fmaxf on MFMA results (NaN operands lose, as maxNum)
@@ -255,7 +258,8 @@ struct LaneState4 {
 
 __device__ __forceinline__ float max4v(const f32x4& v) { return max4(v[0], v[1], v[2], v[3]); }
 
-template <bool DENSE, int NQB, int QPW = 64>
+// INLINE_COMPACT: no function call in the slow path (for kernels that keep asynchronously loaded registers live across it)
+template <bool DENSE, int NQB, int QPW = 64, bool INLINE_COMPACT = false>
 __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& st, f32x4 (&acc)[2][4], uint32_t j, int lane, int wave) {
   const int col = lane & 15, g = lane >> 4;
   const uint32_t tile = a.tile_first + j * a.tile_stride;
@@ -309,11 +313,16 @@ __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& s
         mask &= mask - 1;
         const uint32_t off = __shfl(st.off[qb], L, 64);
         const int cnt = (int)__shfl(st.cnt[qb], L, 64);
-        const uint64_t kth = wave_compact(a.cand + (size_t)__builtin_amdgcn_readfirstlane(off), scratch,
-                                          __builtin_amdgcn_readfirstlane(cnt), a.k, lane);
+        uint64_t* buf = a.cand + (size_t)__builtin_amdgcn_readfirstlane(off);
+        const uint64_t kth = INLINE_COMPACT ? wave_compact_inl(buf, scratch, __builtin_amdgcn_readfirstlane(cnt), a.k, lane)
+                                            : wave_compact(buf, scratch, __builtin_amdgcn_readfirstlane(cnt), a.k, lane);
         if (lane == L) { st.cnt[qb] = a.k; st.thr[qb] = key_score(kth); }
       }
     }
+    // Inlined, the compaction's own global loads are visible to hipcc's waitcnt pass: without a wait IT can see, it treats
+    // them as possibly pending around the caller's loop and answers with s_waitcnt vmcnt(0) inside the hot step (which
+    // drains the LDS-DMA ring on every K step).  vmcnt(0), expcnt / lgkmcnt untouched:
+    if (INLINE_COMPACT) __builtin_amdgcn_s_waitcnt(0x0F70);
   }
 }
 

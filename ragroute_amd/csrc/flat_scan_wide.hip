@@ -245,21 +245,352 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_kernel(const ScanArgs a
   }
 }
 
+
+// ---- deeper pipeline (round 2) ------------------------------------------------------------------------------------------
+// PMC of the kernel above (profiles/r02/wide_*): HBM bytes = algorithmic (nothing re-read from HBM; the query re-stream hits
+// L2), but the waves sit in s_waitcnt / s_barrier for 26 % of their cycles (the d <= 768 kernel: 14 %) and the matrix cores
+// are busy 53 % (77 %).  Cause: vmcnt retires in order and the query loads of step s+1 are issued AFTER the DMA of steps
+// s+1 .. s+LEAD-1, so waiting for those queries at the end of step s also waits for every slab issued before them: whatever
+// the ring depth, only ONE slab (32 KB per CU) is ever in flight past a step boundary - 2/3 of what the d <= 768 kernel keeps.
+// Here the queries are prefetched PD steps ahead into PD+1 register buffers and the slab ring runs PD+1 steps ahead
+// (PD+2 slots), so the closing wait of step s - vmcnt(8 (2 PD - 1)) - leaves PD slabs and PD-1 query sets in flight:
+//   issue order      ... DMA(s+1) | q(s+1) | DMA(s+2) | q(s+2) | ... | DMA(s+PD+1)
+//   closing wait(s)      <- landed ------->| <- may still be in flight ----------->
+// The query buffers are INPUT-ONLY operands of every asm statement that touches them (the loads included): hipcc sees PD+1
+// sets of loop-invariant values that it must keep in fixed registers, and has no definition point inside the loop at which
+// it could insert the register copies that read a destination before its load has landed (the failure mode of "=v" loads
+// whose values are live around a back-edge).  wave_compact is inlined here: a call would spill the caller-saved part of
+// those buffers around it and restore stale copies over loads that landed meanwhile.
+template <typename F>
+__device__ __forceinline__ void query_load_into(const F& dst, uint32_t lane_off, const void* sbase, int imm) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" ::"v"(dst), "v"(lane_off), "s"(sbase), "n"(imm) : "memory");
+}
+template <typename T> struct Mfma16FixedIn;
+#define RR_MFMA16FI(NAME, MNEMONIC, FRAG)                                                                            \
+  template <> struct Mfma16FixedIn<NAME> {                                                                           \
+    template <int R, bool FIRST>                                                                                     \
+    static __device__ __forceinline__ void run(const FRAG& a, const FRAG& b) {                                       \
+      if (FIRST) asm volatile(MNEMONIC " a[%2:%3], %0, %1, 0" ::"v"(a), "v"(b), "n"(R), "n"(R + 3) : RR_ALL_AGPRS);  \
+      else asm volatile(MNEMONIC " a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "n"(R), "n"(R + 3) : RR_ALL_AGPRS); \
+    }                                                                                                                \
+  };
+RR_MFMA16FI(_Float16, "v_mfma_f32_16x16x32_f16", f16x8)
+RR_MFMA16FI(__bf16, "v_mfma_f32_16x16x32_bf16", bf16x8)
+#undef RR_MFMA16FI
+
+#ifndef RR_WIDE_SPREAD
+#define RR_WIDE_SPREAD 0
+#endif
+#ifndef RR_WIDE_ABL
+#define RR_WIDE_ABL 0   // development: timing-only ablations of the step (1 barrier, 2 query loads, 4 DMA, 8 LDS reads, 16 MFMA)
+#endif
+template <typename T, bool DENSE, bool L2, int NQB, int PD>
+__global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArgs a, const int D) {
+  typedef typename Mfma<T>::frag frag;
+  constexpr int NT = DENSE ? 1 : 8;        // 32-row tiles per group
+  constexpr int STEP_BYTES = NT * 4096;    // one K step of one group in LDS
+  constexpr int QB = PD + 1;               // query register buffers
+  constexpr int LEAD = PD + 1;             // K steps the DMA stream runs ahead
+  constexpr int NS = LEAD + 1;             // LDS ring slots
+  constexpr int NF = 4 * NT;               // A fragments per K step: (tile, s2, rb)
+  constexpr int NB = NF < 8 ? NF : 8;
+  constexpr int NQL = 2 * NQB;             // query loads per step and wave
+  constexpr int WAIT_Q = NT * PD + NQL * (PD - 1);  // ops younger than q(s+1) at the end of step s (waves holding queries)
+  constexpr int WAIT_0 = NT * PD;                   // ... for a wave without queries: DMA(s+2) .. DMA(s+LEAD)
+  static_assert(WAIT_Q <= 63, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 15, g = lane >> 4;
+  const int KG = D / 64;                   // even (D is a multiple of 128), >= 14
+  const uint32_t n_tiles = a.n_tiles;
+  const uint32_t n_groups = (n_tiles + NT - 1) / NT;
+
+  uint32_t roff[2];
+  {
+    const int rho = col & 7, p = col >> 3;
+    const int f = ((rho >> 1) & 3) | (p << 2);
+#pragma unroll
+    for (int par = 0; par < 2; ++par) roff[par] = p * 1024 + rho * 128 + (((4 * par + g) ^ f) * 16);
+  }
+  // DMA side: this wave's piece of tile t = rows 8*wave .. +7, lane -> (row rho_w, 16-byte chunk c_w)
+  const int rho_w = lane >> 3, sig = lane & 7;
+  const int f_w = ((rho_w >> 1) & 3) | ((wave & 1) << 2);
+  const int c_w = sig ^ f_w;
+  // Source addresses: one uniform base per (group, K step) + a 32-bit lane offset per tile, recomputed once per group (the
+  // per-piece 64-bit row arithmetic of the round-1 kernel cost 9 VALU + 5 SALU per piece, 8 pieces per step).
+  const size_t row_bytes = (size_t)D * 2;
+  const char* dbase = (const char*)a.xb;   // uniform: first row of the DMA stream's group, + K offset
+  uint32_t voff[NT];
+  auto dma_new_group = [&](uint32_t grp) {
+    if (grp >= n_groups) return;           // the stream runs ahead of the last group: it re-reads that one (valid memory, never used)
+    const uint32_t row_base = (a.tile_first + grp * NT * a.tile_stride) * kTileRows;   // < n_rows: the group's first tile exists
+    dbase = (const char*)a.xb + (size_t)row_base * row_bytes;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      uint32_t j = grp * NT + t;
+      j = j < n_tiles ? j : n_tiles - 1;
+      uint32_t row = (a.tile_first + j * a.tile_stride) * kTileRows + wave * 8 + rho_w;
+      row = row < a.n_rows ? row : a.n_rows - 1;
+      voff[t] = (row - row_base) * (uint32_t)row_bytes + c_w * 16;   // < 256 rows x 16 KB
+    }
+  };
+  auto issue_piece = [&](int kg, int slot, int t) {
+    const char* sb = dbase + (size_t)kg * 128;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voff[t]),
+                                     (__attribute__((address_space(3))) void*)(smem + slot * STEP_BYTES + t * 4096 + wave * 1024), 16, 0, 2);
+  };
+
+  // query blocks of this wave that hold real queries (wave-uniform); a kernel instance serves NQB blocks per wave
+  const int nb = __builtin_amdgcn_readfirstlane((int)a.nq <= wave * 64 ? 0 : ((int)a.nq - wave * 64 + 15) / 16);
+  uint32_t qoff[NQB];
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) {
+    const uint32_t qi = wave * 64 + qb * 16 + col;
+    qoff[qb] = (qi < a.nq ? qi : a.nq - 1) * (uint32_t)(D * 2) + 16 * g;
+  }
+  LaneState4 st;
+  const uint32_t nbuf = gridDim.x * 4;
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) {
+    const uint32_t qi = wave * 64 + qb * 16 + col;
+    st.thr[qb] = DENSE ? 0.f : a.thr[qi];
+#if RR_WIDE_ABL
+    st.thr[qb] = __builtin_inff();   // ablated steps produce garbage scores: nothing may enter the insertion path
+#endif
+    st.cnt[qb] = 0;
+    st.off[qb] = (qi * nbuf + blockIdx.x * 4 + g) * (uint32_t)a.cap;
+  }
+  // the thresholds are global loads: land them here, or their first use inside the loop drains the DMA ring
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(st.thr[0]), "+v"(st.thr[1]), "+v"(st.thr[2]), "+v"(st.thr[3]));
+
+  frag q[QB][NQB][2];                      // [buffer][query block][k slice]: input-only operands everywhere (see above)
+#pragma unroll
+  for (int b = 0; b < QB; ++b)
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+      asm volatile("; query buffer %0" : "=v"(q[b][qb][0]));
+      asm volatile("; query buffer %0" : "=v"(q[b][qb][1]));
+    }
+  auto load_queries = [&](auto buf_tag, int kg) {
+    constexpr int B = decltype(buf_tag)::value;
+    const char* sb = (const char*)a.xq + (size_t)kg * 128;
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+      query_load_into(q[B][qb][0], qoff[qb], sb, 0);
+      query_load_into(q[B][qb][1], qoff[qb], sb, 64);
+    }
+  };
+
+  uint32_t grp = blockIdx.x;               // group being multiplied
+  uint32_t dgrp = blockIdx.x;              // group / K step the DMA stream is at (LEAD steps ahead)
+  int dkg = 0, dslot = 0;
+  auto dma_advance = [&]() {
+    if (++dkg == KG) { dkg = 0; dgrp += gridDim.x; dma_new_group(dgrp); }
+    if (++dslot == NS) dslot = 0;
+  };
+  auto dma_slab = [&]() {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) issue_piece(dkg, dslot, t);
+    dma_advance();
+  };
+  auto closing_wait = [&]() {
+#if (RR_WIDE_ABL & 6) == 6   // timing-only ablations (wrong results): count only what is still issued
+#elif RR_WIDE_ABL & 2
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_0) : "memory");
+#elif RR_WIDE_ABL & 4
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQL * (PD - 1)) : "memory");
+#else
+    if (nb > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_Q) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_0) : "memory");
+#endif
+  };
+  if (grp < n_groups) {
+    dma_new_group(dgrp);
+    // prologue in the steady-state issue order: DMA(0) | q(0) DMA(1) | q(1) DMA(2) | ... | q(PD-1) DMA(PD)
+    dma_slab();
+    static_for<PD>([&](auto i) {
+      if (nb > 0) load_queries(i, decltype(i)::value);
+      dma_slab();
+    });
+    closing_wait();                        // DMA(0) and q(0) have landed
+  }
+
+  int slot = 0, phase = 0, kg = 0;
+  // accumulator of (tile t, row block rb, query block qb): a[16 (2t + rb) + 4 qb ..+3]
+  auto step = [&](auto phase_tag, auto first_tag) {
+    constexpr int P = decltype(phase_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int PN = (P + PD) % QB;      // buffer the queries of step s+PD go to (= the buffer of step s-1)
+#if !(RR_WIDE_ABL & 1)
+    __builtin_amdgcn_s_barrier();          // slab s is complete in LDS (every wave waited for its pieces), slab s-1 is free
+#endif
+    if (nb > 0) {
+      int nkg = kg + PD;
+      if (nkg >= KG) nkg -= KG;            // the next group starts over on the same queries
+#if RR_WIDE_SPREAD
+      // The CU's four waves run this code in lockstep (one barrier per step) and share ONE address unit: issued together, their
+      // vector-memory instructions queue behind each other there and each holds its in-order wave ~60 cycles, with the matrix
+      // pipe idle meanwhile.  So every wave starts its step 16 w cycles (one MFMA time) late, and the 16 VMEM instructions of a
+      // step sit 2 fragments apart in the MFMA stream (queries in the first half, DMA in the second: same queue order).
+      if (wave & 1) asm volatile("s_nop 15" ::: "memory");
+      if (wave & 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+      const char* qsb = (const char*)a.xq + (size_t)nkg * 128;
+#elif !(RR_WIDE_ABL & 2)
+      load_queries(std::integral_constant<int, PN>{}, nkg);
+#endif
+      frag c[NB];
+      const uint32_t ab0 = (uint32_t)(slot * STEP_BYTES) + roff[0], ab1 = (uint32_t)(slot * STEP_BYTES) + roff[1];
+      // fragment f: tile f>>2, k slice (f>>1)&1, row block f&1
+#pragma unroll
+      for (int f = 0; f < NB; ++f) lds_read_frag(c[f], ((f >> 1) & 1) ? ab1 : ab0, (f >> 2) * 4096 + (f & 1) * 2048);
+      static_for<NF>([&](auto fi) {
+        constexpr int f = decltype(fi)::value;
+        constexpr int t = f >> 2, par = (f >> 1) & 1, rb = f & 1;
+        if (NF - f >= NB) lgkm_wait<NB - 1>();
+        else if (NF - f == 7) lgkm_wait<6>();
+        else if (NF - f == 6) lgkm_wait<5>();
+        else if (NF - f == 5) lgkm_wait<4>();
+        else if (NF - f == 4) lgkm_wait<3>();
+        else if (NF - f == 3) lgkm_wait<2>();
+        else if (NF - f == 2) lgkm_wait<1>();
+        else lgkm_wait<0>();
+#if !(RR_WIDE_ABL & 16)
+        static_for<NQB>([&](auto qi) {
+          constexpr int qb = decltype(qi)::value;
+          Mfma16FixedIn<T>::template run<16 * (2 * t + rb) + 4 * qb, FIRST && par == 0>(c[f % NB], q[P][qb][par]);
+        });
+#endif
+#if !(RR_WIDE_ABL & 8)
+        if (f + NB < NF) {
+          constexpr int fn = f + NB;
+          lds_read_frag(c[f % NB], ((fn >> 1) & 1) ? ab1 : ab0, (fn >> 2) * 4096 + (fn & 1) * 2048);
+        }
+#endif
+#if RR_WIDE_SPREAD
+        if (NT == 8) {
+          if constexpr ((f & 1) == 1 && f < 16 && (f >> 2) < NQB)
+            query_load_into(q[PN][f >> 2][(f >> 1) & 1], qoff[f >> 2], qsb, ((f >> 1) & 1) * 64);
+          if constexpr ((f & 1) == 1 && f >= 16) issue_piece(dkg, dslot, (f - 16) >> 1);
+        } else {
+          if (f == 0) load_queries(std::integral_constant<int, PN>{}, nkg);
+          if ((f & 3) == 1) issue_piece(dkg, dslot, f >> 2);
+        }
+#elif !(RR_WIDE_ABL & 4)
+        if ((f & 3) == 1) issue_piece(dkg, dslot, f >> 2);
+#endif
+      });
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) issue_piece(dkg, dslot, t);
+    }
+    dma_advance();
+    if (++slot == NS) slot = 0;
+    closing_wait();                        // slab s+1 (this wave's pieces) and q(s+1) have landed
+  };
+  auto read_tile = [&](auto r_tag, f32x4 (&e)[2][4]) {
+    constexpr int R = decltype(r_tag)::value;
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) e[0][qb] = e[1][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    static_for<NQB>([&](auto qi) {
+      constexpr int qb = decltype(qi)::value;
+      e[0][qb] = read_acc_fixed<R + 4 * qb>();
+      e[1][qb] = read_acc_fixed<R + 16 + 4 * qb>();
+    });
+  };
+  while (grp < n_groups) {
+    const bool first = kg == 0;
+    static_for<QB>([&](auto pi) {
+      if (phase == decltype(pi)::value) {
+        if (first) step(pi, std::true_type{});
+        else step(pi, std::false_type{});
+      }
+    });
+    phase = phase + 1 == QB ? 0 : phase + 1;
+    if (++kg < KG) continue;
+    kg = 0;
+    if (nb > 0) {
+      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<NT>([&](auto ti) {
+        constexpr int t = decltype(ti)::value;
+        const uint32_t j = grp * NT + t;
+        if (j < n_tiles) {
+          f32x4 e[2][4];
+          read_tile(std::integral_constant<int, 32 * t>{}, e);
+          if (L2) {  // rank by q.x - |x|^2/2: the lane's 2 x 4 rows of this tile (rows past the end are filtered by id later)
+            const uint32_t r0 = (a.tile_first + j * a.tile_stride) * kTileRows + 4 * g;
+            f32x4 h0, h1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              h0[i] = a.half_sqnorm[r0 + i < a.n_rows ? r0 + i : a.n_rows - 1];
+              h1[i] = a.half_sqnorm[r0 + 16 + i < a.n_rows ? r0 + 16 + i : a.n_rows - 1];
+            }
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) {
+              e[0][qb] -= h0;
+              e[1][qb] -= h1;
+            }
+          }
+          tile_epilogue16<DENSE, NQB, 64, true>(a, st, e, j, lane, wave);
+        }
+      });
+    }
+    grp += gridDim.x;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+  if (!DENSE) {
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) a.cand_cnt[(wave * 64 + qb * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
+  }
+}
+
+static int wide_pd() {  // RR_WIDE_PD: 0 = the round-1 kernel (one slab in flight), 2 / 3 = query prefetch distance of the deeper pipeline
+  static const int v = [] {
+    const char* e = getenv("RR_WIDE_PD");
+    const int x = e ? atoi(e) : 2;
+    return (x == 0 || x == 2 || x == 3) ? x : 2;
+  }();
+  return v;
+}
+
 template <typename T>
 static hipError_t launch_scan_wide_t(const ScanArgs& a, int D, bool dense, int grid, hipStream_t st) {
   if (D % 128 != 0) return hipErrorInvalidValue;
-  const size_t lds = 3 * (dense ? 1 : 8) * 4096;
+  const int pd = wide_pd();
+  const size_t lds = (size_t)(pd == 0 ? 3 : pd + 2) * (dense ? 1 : 8) * 4096;
+  const bool l2 = a.half_sqnorm != nullptr;
+  const bool few = a.nq <= 16;           // one query block per wave at most: a quarter of the MFMA work
   hipError_t e;
-#define RR_LAUNCH_W(DENSE_, L2_)                                                                                             \
-  {                                                                                                                         \
-    e = hipFuncSetAttribute((const void*)flat_scan_wide_kernel<T, DENSE_, L2_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    if (e != hipSuccess) return e;                                                                                          \
-    hipLaunchKernelGGL((flat_scan_wide_kernel<T, DENSE_, L2_>), dim3(grid), dim3(256), lds, st, a, D);                     \
+#define RR_LAUNCH_KERNEL(...)                                                                                        \
+  {                                                                                                                  \
+    e = hipFuncSetAttribute((const void*)__VA_ARGS__, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+    if (e != hipSuccess) return e;                                                                                   \
+    hipLaunchKernelGGL((__VA_ARGS__), dim3(grid), dim3(256), lds, st, a, D);                                        \
+    return hipGetLastError();                                                                                        \
   }
-  if (a.half_sqnorm) { if (dense) RR_LAUNCH_W(true, true) else RR_LAUNCH_W(false, true) }
-  else { if (dense) RR_LAUNCH_W(true, false) else RR_LAUNCH_W(false, false) }
-#undef RR_LAUNCH_W
-  return hipGetLastError();
+#ifdef RR_WIDE_PD3   // development builds only: the PD = 3 instantiations double the compile time of this unit
+#define RR_PD3_CASE(DENSE_, L2_, NQB_) if (pd == 3) RR_LAUNCH_KERNEL(flat_scan_wide_pd_kernel<T, DENSE_, L2_, NQB_, 3>)
+#else
+#define RR_PD3_CASE(DENSE_, L2_, NQB_)
+#endif
+#define RR_LAUNCH_PD(DENSE_, L2_, NQB_)                                                   \
+  {                                                                                       \
+    RR_PD3_CASE(DENSE_, L2_, NQB_)                                                        \
+    RR_LAUNCH_KERNEL(flat_scan_wide_pd_kernel<T, DENSE_, L2_, NQB_, 2>)                   \
+  }
+  if (pd == 0) {
+    if (l2) { if (dense) RR_LAUNCH_KERNEL(flat_scan_wide_kernel<T, true, true>) else RR_LAUNCH_KERNEL(flat_scan_wide_kernel<T, false, true>) }
+    if (dense) RR_LAUNCH_KERNEL(flat_scan_wide_kernel<T, true, false>) else RR_LAUNCH_KERNEL(flat_scan_wide_kernel<T, false, false>)
+  }
+  if (l2) {
+    if (dense) { if (few) RR_LAUNCH_PD(true, true, 1) else RR_LAUNCH_PD(true, true, 4) }
+    if (few) RR_LAUNCH_PD(false, true, 1) else RR_LAUNCH_PD(false, true, 4)
+  }
+  if (dense) { if (few) RR_LAUNCH_PD(true, false, 1) else RR_LAUNCH_PD(true, false, 4) }
+  if (few) RR_LAUNCH_PD(false, false, 1) else RR_LAUNCH_PD(false, false, 4)
+#undef RR_LAUNCH_PD
+#undef RR_LAUNCH_KERNEL
 }
 
 hipError_t launch_scan_wide(const ScanArgs& a, int dtype, int D, bool dense, int grid, hipStream_t st) {

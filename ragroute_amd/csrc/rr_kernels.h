@@ -9,6 +9,7 @@ namespace rr {
 struct ScanArgs {
   const void* xb;       // [n_rows][D] f16/bf16 corpus (D = padded dim)
   const void* xq;       // [nq][D] queries, same dtype
+  const void* xqs;      // the same 256 queries in MFMA-fragment order (prep kernel): [wave 4][block 4][k slice D/32][lane 64][8 elements]
   const float* thr;     // [256] strict thresholds (filter mode)
   uint64_t* cand;       // [256][grid*2][cap] candidate keys (filter mode)
   uint32_t* cand_cnt;   // [256][grid*2]
@@ -40,9 +41,12 @@ struct SelectArgs {
   uint32_t nbuf, list_ld;
   int cap, k;
 };
-hipError_t launch_init_state(const SelectArgs& a, hipStream_t st);
+// init_state + copy of the query block into fragment order (xqs; nullptr or dim > 768: init only)
+hipError_t launch_prep(const SelectArgs& a, const void* xq, void* xqs, int dim, hipStream_t st);
 hipError_t launch_dense_select(const SelectArgs& a, bool bootstrap, hipStream_t st);
-hipError_t launch_compact(const SelectArgs& a, hipStream_t st);
+// fin != nullptr: this is the last compaction of an inner-product search, emit (D, I) directly (no finalize launch)
+struct FinalizeArgs { float* D; int64_t* I; int64_t id_offset; const uint8_t* mask; int64_t mask_stride; };
+hipError_t launch_compact(const SelectArgs& a, const FinalizeArgs* fin, hipStream_t st);
 hipError_t launch_finalize(const SelectArgs& a, float* D, int64_t* I, int64_t id_offset, const uint8_t* mask, int64_t mask_stride,
                            const void* xq_l2, int dtype, int dim, hipStream_t st);  // xq_l2 != null: emit squared L2 distances
 hipError_t launch_merge_topk(const float* Din, const int64_t* Iin, int nq, int m, int k, int descending,

@@ -20,11 +20,25 @@ __device__ __forceinline__ float next_below(float x) {
   return __uint_as_float((b & 0x80000000u) ? b + 1 : b - 1);
 }
 
-__global__ void init_state_kernel(SelectArgs a) {
-  const uint32_t q = threadIdx.x;
-  if (q < kQueriesPerBlock) {
+// One launch in front of every search: per-query state, and the query block copied into the order in which the d <= 768 scan
+// kernel's waves load their resident MFMA B fragments: [wave][16-query block][32-wide k slice][lane][8 elements], so that each
+// of the 96 loads of a wave (d = 768) is one contiguous KiB instead of 16 rows x 64 B.  (The row-major loads cost ~16 us of
+// every scan launch: 5 launches per search.)  Slots past nq repeat the last query, as the kernel's clamped loads did.
+__global__ __launch_bounds__(256) void prep_kernel(SelectArgs a, const uint4* __restrict__ xq, uint4* __restrict__ xqs, int dim) {
+  if (blockIdx.x == 0) {
+    const uint32_t q = threadIdx.x;
     a.list_cnt[q] = 0;
     a.thr[q] = q < a.nq ? -__builtin_inff() : __builtin_inff();
+  }
+  if (!xqs) return;
+  const int ks2 = dim >> 5;                       // 32-wide k slices
+  const uint32_t total = 16u * ks2 * 64u;          // 16-byte chunks: 4 waves x 4 blocks x ks2 x 64 lanes
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < total; c += gridDim.x * blockDim.x) {
+    const uint32_t lane = c & 63, s2 = (c >> 6) % ks2, wb = (c >> 6) / ks2;   // wb = wave * 4 + block
+    const uint32_t col = lane & 15, g = lane >> 4;
+    uint32_t qi = wb * 16 + col;
+    qi = qi < a.nq ? qi : a.nq - 1;
+    xqs[c] = xq[((size_t)qi * dim + 32 * s2 + 8 * g) >> 3];
   }
 }
 
@@ -123,7 +137,8 @@ __global__ __launch_bounds__(1024) void dense_select_kernel(SelectArgs a) {
   if (threadIdx.x == 0) a.list_cnt[q] = cnt;
 }
 
-__global__ __launch_bounds__(1024) void compact_kernel(SelectArgs a) {
+template <bool FINAL>
+__global__ __launch_bounds__(1024) void compact_kernel(SelectArgs a, FinalizeArgs fin) {
   __shared__ uint64_t keys[kSelectCap];
   __shared__ int scan[16];
   const uint32_t q = blockIdx.x;
@@ -160,7 +175,7 @@ __global__ __launch_bounds__(1024) void compact_kernel(SelectArgs a) {
     offs = base + incl - c;
     return tot;
   };
-  // fast path: every buffer of this query fits next to the running list (the common case: ~7k survivors)
+  // fast path: every buffer of this query fits next to the running list (the common case: a few hundred survivors)
   bool done = false;
   if (a.nbuf <= 1024) {
     int c = 0;
@@ -199,11 +214,26 @@ __global__ __launch_bounds__(1024) void compact_kernel(SelectArgs a) {
     __syncthreads();
   }
   sort_truncate();
-  for (int i = tid; i < k; i += blockDim.x) a.list[(size_t)q * a.list_ld + i] = i < fill ? keys[i] : 0;
+  const uint64_t* sorted = keys;
+  if (FINAL) {
+    const int cnt = (fin.mask && !fin.mask[(size_t)q * fin.mask_stride]) ? 0 : fill;
+    for (int i = tid; i < k; i += blockDim.x) {
+      float sc = -__builtin_inff();
+      int64_t id = -1;
+      if (i < cnt) {
+        sc = key_score(sorted[i]);
+        id = (int64_t)key_id(sorted[i]) + fin.id_offset;
+      }
+      fin.D[(size_t)q * k + i] = sc;
+      fin.I[(size_t)q * k + i] = id;
+    }
+    return;
+  }
+  for (int i = tid; i < k; i += blockDim.x) a.list[(size_t)q * a.list_ld + i] = i < fill ? sorted[i] : 0;
   if (tid == 0) {
     a.list_cnt[q] = fill;
     // strict threshold: every later row has a larger id than the k listed rows, so a tie loses
-    if (fill == k) a.thr[q] = key_score(keys[k - 1]);
+    if (fill == k) a.thr[q] = key_score(sorted[k - 1]);
   }
 }
 
@@ -296,8 +326,10 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const float* Din, cons
   }
 }
 
-hipError_t launch_init_state(const SelectArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(256), 0, st, a);
+hipError_t launch_prep(const SelectArgs& a, const void* xq, void* xqs, int dim, hipStream_t st) {
+  const bool swz = xqs && dim <= kMaxResidentDim && dim % 32 == 0;
+  const int blocks = swz ? (16 * (dim / 32) * 64 + 255) / 256 : 1;
+  hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, st, a, (const uint4*)xq, swz ? (uint4*)xqs : nullptr, dim);
   return hipGetLastError();
 }
 hipError_t launch_dense_select(const SelectArgs& a, bool bootstrap, hipStream_t st) {
@@ -305,8 +337,9 @@ hipError_t launch_dense_select(const SelectArgs& a, bool bootstrap, hipStream_t 
   else hipLaunchKernelGGL(dense_select_kernel<false>, dim3(kQueriesPerBlock), dim3(1024), 0, st, a);
   return hipGetLastError();
 }
-hipError_t launch_compact(const SelectArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(compact_kernel, dim3(kQueriesPerBlock), dim3(1024), 0, st, a);
+hipError_t launch_compact(const SelectArgs& a, const FinalizeArgs* fin, hipStream_t st) {
+  if (fin) hipLaunchKernelGGL(compact_kernel<true>, dim3(kQueriesPerBlock), dim3(1024), 0, st, a, *fin);
+  else hipLaunchKernelGGL(compact_kernel<false>, dim3(kQueriesPerBlock), dim3(1024), 0, st, a, FinalizeArgs{});
   return hipGetLastError();
 }
 hipError_t launch_finalize(const SelectArgs& a, float* D, int64_t* I, int64_t id_offset, const uint8_t* mask, int64_t mask_stride,
