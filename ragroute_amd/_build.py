@@ -18,7 +18,7 @@ HEADERS = ["rr_common.h", "rr_kernels.h", "rr_sort.h", "flat_scan_common.h"]
 LLVM_BIN = os.environ.get("RR_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 
 # kernels whose accumulators live in hard-wired AGPRs named only inside asm text
-FIXED_AGPR_KERNELS = ("flat_scan_wide_kernel",)
+FIXED_AGPR_KERNELS = ("flat_scan_wide",)   # flat_scan_wide_kernel, _pd_kernel, wide8_kernel
 
 
 def _flags():

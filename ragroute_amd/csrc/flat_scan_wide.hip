@@ -545,6 +545,248 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
   }
 }
 
+
+// ---- two waves per SIMD (round 2) ---------------------------------------------------------------------------------------
+// Timing-only ablations of the kernel above (RR_WIDE_ABL; 2M x 4096, 256 queries, whole search): 4.30 ms as is, 3.70 without
+// the query loads, 3.23 without the DMA instructions, 2.63 without both (LDS reads + MFMA + barrier alone), 4.12 without the
+// barrier.  The 16 vector-memory instructions of a step cost ~40 % of it: each holds its in-order wave ~60 cycles at issue -
+// whether or not the other waves issue theirs at the same moment (staggering them bought 0-3 %) - and with ONE wave per SIMD
+// the matrix pipe idles meanwhile.  So: 512 threads, TWO waves per SIMD, each wave 256 rows x 32 queries (128 hard-wired
+// AGPR accumulators, 128 VGPRs): while one wave of a SIMD is stuck issuing a load, its partner's MFMAs use the pipe.  Same
+// LDS image, same ring and queue discipline as above with 4 DMA pieces and 4 query loads per wave and step; every A fragment
+// is read from LDS by 8 waves instead of 4 (256 KB per step and CU = half of the LDS read rate).
+#define RR_AGPRS_128 "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
+template <typename T> struct Mfma16Fixed128;
+#define RR_MFMA16F128(NAME, MNEMONIC, FRAG)                                                                          \
+  template <> struct Mfma16Fixed128<NAME> {                                                                          \
+    template <int R, bool FIRST>                                                                                     \
+    static __device__ __forceinline__ void run(const FRAG& a, const FRAG& b) {                                       \
+      if (FIRST) asm volatile(MNEMONIC " a[%2:%3], %0, %1, 0" ::"v"(a), "v"(b), "n"(R), "n"(R + 3) : RR_AGPRS_128);  \
+      else asm volatile(MNEMONIC " a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "n"(R), "n"(R + 3) : RR_AGPRS_128); \
+    }                                                                                                                \
+  };
+RR_MFMA16F128(_Float16, "v_mfma_f32_16x16x32_f16", f16x8)
+RR_MFMA16F128(__bf16, "v_mfma_f32_16x16x32_bf16", bf16x8)
+#undef RR_MFMA16F128
+template <int R>
+__device__ __forceinline__ f32x4 read_acc_fixed128() {
+  f32x4 v;
+  asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
+               : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]) : "n"(R), "n"(R + 1), "n"(R + 2), "n"(R + 3) : RR_AGPRS_128);
+  return v;
+}
+
+#ifndef RR_WIDE8_RING
+#define RR_WIDE8_RING 8   // A fragments in flight from LDS per wave
+#endif
+template <typename T, bool L2, int NQB, int PD>
+__global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, const int D) {
+  typedef typename Mfma<T>::frag frag;
+  constexpr int NT = 8;                    // 32-row tiles per group
+  constexpr int STEP_BYTES = NT * 4096;    // one K step of one group in LDS
+  constexpr int QPW = 32;                  // queries per wave
+  constexpr int QB = PD + 1, LEAD = PD + 1, NS = LEAD + 1;
+  constexpr int NF = 4 * NT;               // A fragments per K step: (tile, s2, rb)
+  constexpr int NB = RR_WIDE8_RING;
+  constexpr int NPW = 4;                   // DMA pieces per wave and slab (32 pieces over 8 waves)
+  constexpr int NQL = 2 * NQB;             // query loads per step and wave
+  constexpr int WAIT_Q = NPW * PD + NQL * (PD - 1);
+  constexpr int WAIT_0 = NPW * PD;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..7
+  const int col = lane & 15, g = lane >> 4;
+  const int KG = D / 64;
+  const uint32_t n_tiles = a.n_tiles;
+  const uint32_t n_groups = (n_tiles + NT - 1) / NT;
+
+  uint32_t roff[2];
+  {
+    const int rho = col & 7, p = col >> 3;
+    const int f = ((rho >> 1) & 3) | (p << 2);
+#pragma unroll
+    for (int par = 0; par < 2; ++par) roff[par] = p * 1024 + rho * 128 + (((4 * par + g) ^ f) * 16);
+  }
+  // DMA side: wave w fills row octet o = w & 3 (rows 8 o .. +7) of tiles 4 (w >> 2) .. +3; lane -> (row rho_w, 16-byte chunk c_w)
+  const int oct = wave & 3, tbase = (wave >> 2) * 4;
+  const int rho_w = lane >> 3, sig = lane & 7;
+  const int f_w = ((rho_w >> 1) & 3) | ((oct & 1) << 2);
+  const int c_w = sig ^ f_w;
+  const size_t row_bytes = (size_t)D * 2;
+  const char* dbase = (const char*)a.xb;
+  uint32_t voff[NPW];
+  auto dma_new_group = [&](uint32_t grp) {
+    if (grp >= n_groups) return;
+    const uint32_t row_base = (a.tile_first + grp * NT * a.tile_stride) * kTileRows;
+    dbase = (const char*)a.xb + (size_t)row_base * row_bytes;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      uint32_t j = grp * NT + tbase + i;
+      j = j < n_tiles ? j : n_tiles - 1;
+      uint32_t row = (a.tile_first + j * a.tile_stride) * kTileRows + oct * 8 + rho_w;
+      row = row < a.n_rows ? row : a.n_rows - 1;
+      voff[i] = (row - row_base) * (uint32_t)row_bytes + c_w * 16;
+    }
+  };
+  auto issue_piece = [&](int kg, int slot, int i) {
+    const char* sb = dbase + (size_t)kg * 128;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voff[i]),
+                                     (__attribute__((address_space(3))) void*)(smem + slot * STEP_BYTES + (tbase + i) * 4096 + oct * 1024), 16, 0, 2);
+  };
+
+  const int nb = __builtin_amdgcn_readfirstlane((int)a.nq <= wave * QPW ? 0 : ((int)a.nq - wave * QPW + 15) / 16);
+  uint32_t qoff[NQB];
+#pragma unroll
+  for (int qb = 0; qb < NQB; ++qb) {
+    const uint32_t qi = wave * QPW + qb * 16 + col;
+    qoff[qb] = (qi < a.nq ? qi : a.nq - 1) * (uint32_t)(D * 2) + 16 * g;
+  }
+  LaneState4 st;
+  const uint32_t nbuf = gridDim.x * 4;
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) {
+    const uint32_t qi = wave * QPW + (qb & 1) * 16 + col;
+    st.thr[qb] = qb < 2 ? a.thr[qi] : 0.f;
+#if RR_WIDE_ABL
+    st.thr[qb] = __builtin_inff();
+#endif
+    st.cnt[qb] = 0;
+    st.off[qb] = (qi * nbuf + blockIdx.x * 4 + g) * (uint32_t)a.cap;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(st.thr[0]), "+v"(st.thr[1]));
+
+  frag q[QB][NQB][2];
+#pragma unroll
+  for (int b = 0; b < QB; ++b)
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+      asm volatile("; query buffer %0" : "=v"(q[b][qb][0]));
+      asm volatile("; query buffer %0" : "=v"(q[b][qb][1]));
+    }
+  auto load_queries = [&](auto buf_tag, int kg) {
+    constexpr int B = decltype(buf_tag)::value;
+    const char* sb = (const char*)a.xq + (size_t)kg * 128;
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+      query_load_into(q[B][qb][0], qoff[qb], sb, 0);
+      query_load_into(q[B][qb][1], qoff[qb], sb, 64);
+    }
+  };
+
+  uint32_t grp = blockIdx.x, dgrp = blockIdx.x;
+  int dkg = 0, dslot = 0;
+  auto dma_advance = [&]() {
+    if (++dkg == KG) { dkg = 0; dgrp += gridDim.x; dma_new_group(dgrp); }
+    if (++dslot == NS) dslot = 0;
+  };
+  auto dma_slab = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) issue_piece(dkg, dslot, i);
+    dma_advance();
+  };
+  auto closing_wait = [&]() {
+    if (nb > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_Q) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_0) : "memory");
+  };
+  if (grp < n_groups) {
+    dma_new_group(dgrp);
+    dma_slab();
+    static_for<PD>([&](auto i) {
+      if (nb > 0) load_queries(i, decltype(i)::value);
+      dma_slab();
+    });
+    closing_wait();
+  }
+
+  int slot = 0, phase = 0, kg = 0;
+  // accumulator of (tile t, row block rb, query block qb): a[8 (2t + rb) + 4 qb ..+3]
+  auto step = [&](auto phase_tag, auto first_tag) {
+    constexpr int P = decltype(phase_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int PN = (P + PD) % QB;
+    __builtin_amdgcn_s_barrier();
+    if (nb > 0) {
+      int nkg = kg + PD;
+      if (nkg >= KG) nkg -= KG;
+      load_queries(std::integral_constant<int, PN>{}, nkg);
+      frag c[NB];
+      const uint32_t ab0 = (uint32_t)(slot * STEP_BYTES) + roff[0], ab1 = (uint32_t)(slot * STEP_BYTES) + roff[1];
+#pragma unroll
+      for (int f = 0; f < NB; ++f) lds_read_frag(c[f], ((f >> 1) & 1) ? ab1 : ab0, (f >> 2) * 4096 + (f & 1) * 2048);
+      static_for<NF>([&](auto fi) {
+        constexpr int f = decltype(fi)::value;
+        constexpr int t = f >> 2, par = (f >> 1) & 1, rb = f & 1;
+        constexpr int LEFT = NF - f;       // fragments not yet consumed; min(LEFT, NB) - 1 reads may stay in flight
+        lgkm_wait<(LEFT >= NB ? NB : LEFT) - 1>();
+        static_for<NQB>([&](auto qi) {
+          constexpr int qb = decltype(qi)::value;
+          Mfma16Fixed128<T>::template run<8 * (2 * t + rb) + 4 * qb, FIRST && par == 0>(c[f % NB], q[P][qb][par]);
+        });
+        if constexpr (f + NB < NF) {
+          constexpr int fn = f + NB;
+          lds_read_frag(c[f % NB], ((fn >> 1) & 1) ? ab1 : ab0, (fn >> 2) * 4096 + (fn & 1) * 2048);
+        }
+        if constexpr ((f & 7) == 3) issue_piece(dkg, dslot, f >> 3);
+      });
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPW; ++i) issue_piece(dkg, dslot, i);
+    }
+    dma_advance();
+    if (++slot == NS) slot = 0;
+    closing_wait();
+  };
+  while (grp < n_groups) {
+    const bool first = kg == 0;
+    static_for<QB>([&](auto pi) {
+      if (phase == decltype(pi)::value) {
+        if (first) step(pi, std::true_type{});
+        else step(pi, std::false_type{});
+      }
+    });
+    phase = phase + 1 == QB ? 0 : phase + 1;
+    if (++kg < KG) continue;
+    kg = 0;
+    if (nb > 0) {
+      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<NT>([&](auto ti) {
+        constexpr int t = decltype(ti)::value;
+        const uint32_t j = grp * NT + t;
+        if (j < n_tiles) {
+          f32x4 e[2][4];
+#pragma unroll
+          for (int qb = 0; qb < 4; ++qb) e[0][qb] = e[1][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+          static_for<NQB>([&](auto qi) {
+            constexpr int qb = decltype(qi)::value;
+            e[0][qb] = read_acc_fixed128<16 * t + 4 * qb>();
+            e[1][qb] = read_acc_fixed128<16 * t + 8 + 4 * qb>();
+          });
+          if (L2) {
+            const uint32_t r0 = (a.tile_first + j * a.tile_stride) * kTileRows + 4 * g;
+            f32x4 h0, h1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              h0[i] = a.half_sqnorm[r0 + i < a.n_rows ? r0 + i : a.n_rows - 1];
+              h1[i] = a.half_sqnorm[r0 + 16 + i < a.n_rows ? r0 + 16 + i : a.n_rows - 1];
+            }
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) {
+              e[0][qb] -= h0;
+              e[1][qb] -= h1;
+            }
+          }
+          tile_epilogue16<false, NQB, QPW, true>(a, st, e, j, lane, wave);
+        }
+      });
+    }
+    grp += gridDim.x;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) a.cand_cnt[(wave * QPW + qb * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
+}
+
 static int wide_pd() {  // RR_WIDE_PD: 0 = the round-1 kernel (one slab in flight), 2 / 3 = query prefetch distance of the deeper pipeline
   static const int v = [] {
     const char* e = getenv("RR_WIDE_PD");
@@ -552,6 +794,17 @@ static int wide_pd() {  // RR_WIDE_PD: 0 = the round-1 kernel (one slab in fligh
     return (x == 0 || x == 2 || x == 3) ? x : 2;
   }();
   return v;
+}
+
+// Filter launches: two waves per SIMD (flat_scan_wide8_kernel) up to d = 2048, one above.  Measured, 2M rows x 256 queries, whole
+// search: d = 1024 3.53 vs 3.43 TB/s, 1536 3.61 vs 3.50, 2048 3.74 vs 3.64, 4096 3.74 vs 3.82.  RR_WIDE_WAVES=4|8 forces one.
+static int wide_waves(int D) {
+  static const int forced = [] {
+    const char* e = getenv("RR_WIDE_WAVES");
+    const int v = e ? atoi(e) : 0;
+    return (v == 4 || v == 8) ? v : 0;
+  }();
+  return forced ? forced : (D <= 2048 ? 8 : 4);
 }
 
 template <typename T>
@@ -578,6 +831,19 @@ static hipError_t launch_scan_wide_t(const ScanArgs& a, int D, bool dense, int g
   {                                                                                       \
     RR_PD3_CASE(DENSE_, L2_, NQB_)                                                        \
     RR_LAUNCH_KERNEL(flat_scan_wide_pd_kernel<T, DENSE_, L2_, NQB_, 2>)                   \
+  }
+  if (!dense && pd != 0 && wide_waves(D) == 8) {
+    hipError_t e8;
+#define RR_LAUNCH_8(...)                                                                                             \
+  {                                                                                                                  \
+    e8 = hipFuncSetAttribute((const void*)__VA_ARGS__, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+    if (e8 != hipSuccess) return e8;                                                                                 \
+    hipLaunchKernelGGL((__VA_ARGS__), dim3(grid), dim3(512), lds, st, a, D);                                        \
+    return hipGetLastError();                                                                                        \
+  }
+    if (l2) { if (few) RR_LAUNCH_8(flat_scan_wide8_kernel<T, true, 1, 2>) else RR_LAUNCH_8(flat_scan_wide8_kernel<T, true, 2, 2>) }
+    if (few) RR_LAUNCH_8(flat_scan_wide8_kernel<T, false, 1, 2>) else RR_LAUNCH_8(flat_scan_wide8_kernel<T, false, 2, 2>)
+#undef RR_LAUNCH_8
   }
   if (pd == 0) {
     if (l2) { if (dense) RR_LAUNCH_KERNEL(flat_scan_wide_kernel<T, true, true>) else RR_LAUNCH_KERNEL(flat_scan_wide_kernel<T, false, true>) }

@@ -1,0 +1,70 @@
+"""GPU: no kernel may read past the end of the corpus or of the query block.
+
+Both tensors are placed flush against the END of a dedicated device allocation (a multiple of 2 MiB, which PyTorch's
+caching allocator requests from the driver as one segment of exactly that size), so a read beyond the last byte leaves
+the mapping and faults instead of silently reading a neighbour.  Results are also checked against the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import int_data
+
+pytestmark = pytest.mark.gpu
+SEG = 2 << 20
+
+
+def _flush_to_end(t, dev):
+    """Copy of tensor t whose last byte is the last byte of a fresh device segment."""
+    nbytes = t.numel() * t.element_size()
+    total = max(12 * (1 << 20), -(-nbytes // SEG) * SEG + SEG) // SEG * SEG   # > 10 MiB: a segment of its own
+    buf = torch.empty(total, dtype=torch.uint8, device=dev)
+    view = buf[total - nbytes:].view(t.dtype).view(t.shape)
+    view.copy_(t)
+    return buf, view
+
+
+def _run_cases(dev, cases):
+    from oracle import oracle as O
+    from ragroute_amd.flat_index import FlatIndex
+    rng = np.random.default_rng(17)
+    for d, n, nqs in cases:
+        xb = int_data(rng, n, d)
+        idx = FlatIndex(d, device=dev)
+        dim = idx.dim
+        xb_h = torch.zeros((n, dim), dtype=torch.float16)
+        xb_h[:, :d] = torch.from_numpy(xb).half()
+        keep_b, xb_dev = _flush_to_end(xb_h, dev)
+        idx.adopt(xb_dev)
+        for nq in nqs:
+            xq = int_data(rng, nq, d)
+            xq_h = torch.zeros((nq, dim), dtype=torch.float16)
+            xq_h[:, :d] = torch.from_numpy(xq).half()
+            keep_q, xq_dev = _flush_to_end(xq_h, dev)
+            D, I = idx.search_prepared(xq_dev, 10)
+            torch.cuda.synchronize()
+            Dr, Ir = O.flat_search_ip(xb, xq, 10)
+            assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr), (d, n, nq)
+            del keep_q
+        del keep_b
+
+
+CASES = [(768, 33_000, (1, 4, 100, 256)), (384, 20_011, (3, 256)), (1024, 40_000, (1, 4, 128, 129, 256)),
+         (1536, 20_000, (7, 200)), (2048, 30_000, (1, 4, 17, 256)), (4096, 12_345, (1, 5, 256))]
+
+
+def test_no_read_past_the_end_of_corpus_or_queries(gpu):
+    _run_cases(gpu, CASES)
+
+
+@pytest.mark.parametrize("waves", ["4", "8"])
+def test_no_read_past_the_end_both_wide_row_flavours(gpu, waves):
+    """RR_WIDE_WAVES is read once per process: the forced flavours run in a child process."""
+    code = ("import torch, tests.test_guard_pages_gpu as t; "
+            "t._run_cases(torch.device('cuda:0'), [(1024, 40_000, (200, 256)), (2048, 30_000, (1, 4, 17, 256)), (4096, 12_345, (1, 5, 256))]); print('ok')")
+    env = dict(os.environ, RR_WIDE_WAVES=waves, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stderr[-2000:]

@@ -1,6 +1,6 @@
 """Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into profiles/traffic.json.
 
-    python tools_pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps_in_run> <out.json>
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps_in_run> <out.json> [rows dim batch k dtype lib_version]
 
 HBM bytes per launch of the scan kernel, as MI355X_MICROARCH.md prescribes: separate --pmc passes; FETCH_SIZE and
 WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of a wide coalesced stream, so it is doubled;
@@ -25,7 +25,12 @@ def main():
     n = len(f)
     fetch_bytes = sum(f.values()) * 1024 * 2      # gfx950: FETCH_SIZE = 1/2 of the streamed bytes
     write_bytes = sum(w.values()) * 1024
-    res = {"rows": 10_000_000, "dim": 768, "batch": 256, "scan_launches": n, "steps_profiled": steps,
+    extra = sys.argv[5:]
+    rows, dim, batch, k = (int(x) for x in (extra + ["10000000", "768", "256", "32"])[:4]) if len(extra) < 4 else (int(x) for x in extra[:4])
+    dtype = extra[4] if len(extra) > 4 else "fp16"
+    lib_version = int(extra[5]) if len(extra) > 5 else None
+    res = {"rows": rows, "dim": dim, "batch": batch, "k": k, "dtype": dtype, "lib_version": lib_version,
+           "scan_launches": n, "steps_profiled": steps,
            "fetch_bytes_per_launch_corrected": fetch_bytes / n, "write_bytes_per_launch": write_bytes / max(1, len(w)),
            "hbm_bytes_per_launch": fetch_bytes / n + write_bytes / max(1, len(w)),
            "hbm_bytes_per_search": (fetch_bytes / n + write_bytes / max(1, len(w))) * n / steps,
