@@ -183,10 +183,12 @@ def test_data_source_glue_matches_reference_golden(gpu, tmp_path, monkeypatch):
             assert [list(d) for d in docs] == want["docs"]
 
 
-def test_batched_serving_equals_per_query_replies(gpu):
-    """40 concurrent requests through DataSource.handle_query are coalesced into a few GPU batches and every reply
-    equals the single-query retrieve of the reference call shape (data_source.py:113-132)."""
+def test_batched_serving_replies_match_the_oracle(gpu):
+    """40 concurrent requests through DataSource.handle_query are coalesced into a few GPU batches and every reply holds what
+    the reference's single-query path returns for that request (data_source.py:113-132, 165-194) — expected values from the
+    oracle's search + the row -> metadata -> chunk lookups, not from the object's own single-query method."""
     import asyncio
+    from oracle import oracle as O
     from ragroute_amd import data_source as DS
     xb, metadatas, chunks = synth_medrag_corpus(5)
     ds = DS.DataSource(0, "medrag", "textbooks")
@@ -198,10 +200,13 @@ def test_batched_serving_equals_per_query_replies(gpu):
         return await asyncio.gather(*[ds.handle_query({"id": f"q{i}", "embedding": q.tolist()}) for i, q in enumerate(queries)])
     replies = asyncio.run(go())
     assert ds._batcher.items_run == 40 and ds._batcher.batches_run <= 4
-    for i, (q, rep) in enumerate(zip(queries, replies)):
-        ids, docs, scores = ds.retrieve_docs_medrag(q.reshape(1, -1), 32)
+    Dr, Ir = O.flat_search_ip(xb, queries, 32)
+    for i, rep in enumerate(replies):
+        want_idx = [metadatas[int(r)] for r in Ir[i]]                                   # data_source.py:190
+        want_docs = [chunks[m["source"]][m["index"]] for m in want_idx]                # data_source.py:166-183
         assert rep["query_id"] == f"q{i}" and rep["client_id"] == 0 and rep["name"] == "textbooks"
-        assert rep["indices"] == ids and rep["docs"] == docs and rep["scores"] == scores
+        assert rep["indices"] == want_idx and rep["docs"] == want_docs
+        assert rep["scores"] == [float(s) for s in Dr[i]]                              # integer data: exact
         json.dumps(rep)  # wire format must be JSON-serialisable
 
 
