@@ -155,6 +155,13 @@ typedef struct rr_router_weights {
  *   d_mask   u8  [nq][C]   1 where sigmoid(logit) > prob_threshold */
 int rr_router_mlp(const rr_router_weights* w, const float* d_xq, int nq, float* d_logits, uint8_t* d_mask,
                   void* stream);
+/* The same operator for BATCHES (what the batched router service, the pipeline and bench.py call): from 32 queries on, fc1
+ * and fc2 run on the f32 matrix cores with 64 queries sharing every weight load; partial sums of fc1 live in a caller-provided
+ * device workspace of rr_router_workspace_bytes(w, nq) bytes (0 for batches that take the small-batch kernel above, for which
+ * d_ws may be NULL).  The reference has no batched form: it forwards one query at a time (router.py:207-219, 241-283). */
+size_t rr_router_workspace_bytes(const rr_router_weights* w, int nq);
+int rr_router_mlp_ws(const rr_router_weights* w, const float* d_xq, int nq, float* d_logits, uint8_t* d_mask, void* d_ws,
+                     size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

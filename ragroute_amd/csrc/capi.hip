@@ -398,4 +398,25 @@ int rr_router_mlp(const rr_router_weights* w, const float* xq, int nq, float* lo
   return e == hipSuccess ? RR_OK : hip_fail(e, "rr_router_mlp");
 }
 
+size_t rr_router_workspace_bytes(const rr_router_weights* w, int nq) {
+  if (!w || nq < 0 || w->n_sources < 1 || w->d_max < 1 || w->n_models < 1 || w->d_max > 8448) return 0;
+  return rr::router_workspace_bytes(w, nq);
+}
+
+int rr_router_mlp_ws(const rr_router_weights* w, const float* xq, int nq, float* logits, uint8_t* mask, void* ws, size_t ws_bytes,
+                     void* stream) {
+  if (!w || nq < 0) return fail(RR_ERR_INVALID, "rr_router_mlp_ws: bad arguments%s");
+  if (w->n_sources < 1 || w->d_max < 1 || w->n_models < 1 || w->d_max > 8448)
+    return fail(RR_ERR_INVALID, "rr_router_mlp_ws: bad weight header%s");
+  if (nq == 0) return RR_OK;
+  if (!xq || !logits || !mask || !w->w1q || !w->c1 || !w->w2 || !w->w3 || !w->model_of_source)
+    return fail(RR_ERR_INVALID, "rr_router_mlp_ws: null pointer%s");
+  const size_t need = rr::router_workspace_bytes(w, nq);
+  if (need == 0)  // small batch: the latency-oriented kernel, no workspace
+    return rr_router_mlp(w, xq, nq, logits, mask, stream);
+  if (!ws || ws_bytes < need) return fail(RR_ERR_WORKSPACE, "rr_router_mlp_ws: workspace smaller than rr_router_workspace_bytes%s");
+  hipError_t e = rr::launch_router_mlp_ws(w, xq, nq, logits, mask, ws, (hipStream_t)stream);
+  return e == hipSuccess ? RR_OK : hip_fail(e, "rr_router_mlp_ws");
+}
+
 }  // extern "C"

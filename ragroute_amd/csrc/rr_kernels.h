@@ -71,5 +71,9 @@ hipError_t launch_rescore(const void* xb, const void* xq, int dtype, int dim, in
 // router.hip
 hipError_t launch_router_mlp(const rr_router_weights* w, const float* xq, int nq, float* logits, uint8_t* mask,
                              hipStream_t st);
+constexpr int kRouterMfmaMinQueries = 32;   // batches from this size take the matrix-core form (needs a workspace)
+size_t router_workspace_bytes(const rr_router_weights* w, int nq);
+hipError_t launch_router_mlp_ws(const rr_router_weights* w, const float* xq, int nq, float* logits, uint8_t* mask, void* ws,
+                                hipStream_t st);
 
 }  // namespace rr

@@ -117,6 +117,7 @@ class FoldedRouter:
         self.n_sources, self.d_max = c1.shape[0], w1q.shape[0]
         self.n_models = int(max(model_of_source)) + 1
         self.device = dev
+        self._ws = None   # fc1 partial sums of the batched (matrix-core) form, grown on demand
         self.t = {"w1q": f(w1q), "c1": f(c1), "ln1_g": f(sd["ln1.weight"]), "ln1_b": f(sd["ln1.bias"]),
                   "w2": f(sd["fc2.weight"].T), "b2": f(sd["fc2.bias"]), "ln2_g": f(sd["ln2.weight"]), "ln2_b": f(sd["ln2.bias"]),
                   "w3": f(sd["fc3.weight"].reshape(-1)),
@@ -148,8 +149,12 @@ class FoldedRouter:
         nq = xq.shape[0]
         logits = torch.empty((nq, self.n_sources), dtype=torch.float32, device=self.device)
         mask = torch.empty((nq, self.n_sources), dtype=torch.uint8, device=self.device)
-        check(lib().rr_router_mlp(ctypes.byref(self.struct), xq.data_ptr(), nq, logits.data_ptr(), mask.data_ptr(), _stream_ptr()),
-              "rr_router_mlp")
+        need = lib().rr_router_workspace_bytes(ctypes.byref(self.struct), nq)   # 0: small batch, latency-oriented kernel
+        if need > (self._ws.numel() if self._ws is not None else 0):
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        check(lib().rr_router_mlp_ws(ctypes.byref(self.struct), xq.data_ptr(), nq, logits.data_ptr(), mask.data_ptr(),
+                                     self._ws.data_ptr() if need else None, self._ws.numel() if need else 0, _stream_ptr()),
+              "rr_router_mlp_ws")
         return logits, mask.view(torch.bool)
 
 

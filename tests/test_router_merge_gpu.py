@@ -375,3 +375,33 @@ def test_data_source_serves_an_l2_index_wider_than_768(gpu, tmp_path, monkeypatc
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
     ids, docs, scores = ds.retrieve_docs_fed4rag(xq[:1], 10)
     assert ids == [docids[i] for i in Ir[0]] and scores == []
+
+
+@pytest.mark.parametrize("dataset,nq", [("feb4rag", 256), ("feb4rag", 45), ("wikipedia", 200), ("medrag", 256)])
+def test_router_batched_matrix_core_form_vs_oracle(gpu, dataset, nq):
+    """Batches of >= 32 queries take the f32 matrix-core kernels (router_fc1_kernel + router_head_kernel; medrag's small router
+    keeps the latency-oriented kernel): logits within LOGIT_TOL of the oracle's per-query forward (router.py:241-275), decisions
+    identical off the boundary, bit-identical from run to run, ragged batch sizes."""
+    from oracle import oracle as O
+    from ragroute_amd import config as C
+    r, case = _router(dataset, 33)
+    rng = np.random.default_rng(nq)
+    sources, d_max = case["sources"], case["d_max"]
+    dims = {m: len(v) for m, v in case["queries"][0].items()}
+    batch = {m: rng.standard_normal((nq, dm)).astype(np.float32) for m, dm in dims.items()}
+    xq = r.pack_queries(batch)
+    L, M = r.route_batch(xq)
+    L2, M2 = r.route_batch(xq)
+    assert torch.equal(L, L2) and torch.equal(M, M2)
+    L, M = L.cpu().numpy(), M.cpu().numpy()
+    model_of = {s: C.EMBEDDING_MODELS_PER_DATA_SOURCE[dataset][s][0] for s in sources}
+    ids = {"medrag": C.MEDRAG_SOURCE_TO_ID, "feb4rag": C.FEB4RAG_SOURCE_TO_ID, "wikipedia": None}[dataset]
+    cents = {s: np.pad(case["centroids"][s], (0, d_max - len(case["centroids"][s]))) for s in sources}
+    mean, scale = case["scaler"] if case["scaler"] is not None else (None, None)
+    thr = 0.4924 if dataset == "medrag" else 0.5
+    boundary = np.log(thr / (1 - thr))
+    for i in range(0, nq, 7):
+        want = O.router_logits(dataset, sources, model_of, ids, d_max, {m: batch[m][i] for m in dims}, cents, case["sd"], mean, scale)
+        assert np.abs(L[i] - want).max() < LOGIT_TOL, (i, np.abs(L[i] - want).max())
+        off = np.abs(want - boundary) > LOGIT_TOL
+        assert np.array_equal(M[i][off], (want > boundary)[off])
