@@ -1,12 +1,11 @@
-"""Drop-in shim: put this directory's parent on PYTHONPATH *before* the reference checkout and set
-RAGROUTE_REFERENCE_DIR to that checkout; `python $RAGROUTE_REFERENCE_DIR/main.py ...` then runs unchanged, with
+"""Drop-in shim: with this directory's parent FIRST on sys.path and RAGROUTE_REFERENCE_DIR set to the reference checkout, the
+reference's main.py runs unchanged (compat/run_main.py arranges both: `python main.py` itself would put the checkout first), with
 
     ragroute.router / ragroute.data_source / ragroute.rerank      -> ragroute_amd (MI355X kernels)
     every other ragroute.* module (config, http_server, ragroute, queue_manager, llm_message, models, ...)
                                                                    -> the reference's own files
 
-    PYTHONPATH=/path/to/this/repo/compat:/path/to/this/repo RAGROUTE_REFERENCE_DIR=/path/to/ragroute \\
-        python /path/to/ragroute/main.py --dataset medrag --routing all --disable-llm
+    RAGROUTE_REFERENCE_DIR=/path/to/ragroute python /path/to/this/repo/compat/run_main.py --dataset medrag --routing all --disable-llm
 """
 import os
 
