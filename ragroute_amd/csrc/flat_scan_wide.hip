@@ -279,7 +279,7 @@ RR_MFMA16FI(__bf16, "v_mfma_f32_16x16x32_bf16", bf16x8)
 #undef RR_MFMA16FI
 
 #ifndef RR_WIDE_SPREAD
-#define RR_WIDE_SPREAD 0
+#define RR_WIDE_SPREAD 1   // measured at d = 4096, 2M rows, 256 queries: 0.496 vs 0.480 of the HBM peak (scan launches)
 #endif
 #ifndef RR_WIDE_ABL
 #define RR_WIDE_ABL 0   // development: timing-only ablations of the step (1 barrier, 2 query loads, 4 DMA, 8 LDS reads, 16 MFMA)
@@ -576,6 +576,9 @@ __device__ __forceinline__ f32x4 read_acc_fixed128() {
   return v;
 }
 
+#ifndef RR_WIDE8_SPREAD
+#define RR_WIDE8_SPREAD 0
+#endif
 #ifndef RR_WIDE8_RING
 #define RR_WIDE8_RING 8   // A fragments in flight from LDS per wave
 #endif
@@ -708,7 +711,11 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
     if (nb > 0) {
       int nkg = kg + PD;
       if (nkg >= KG) nkg -= KG;
+#if RR_WIDE8_SPREAD
+      const char* qsb = (const char*)a.xq + (size_t)nkg * 128;   // query loads go into the first half of the MFMA stream, 4 fragments apart
+#else
       load_queries(std::integral_constant<int, PN>{}, nkg);
+#endif
       frag c[NB];
       const uint32_t ab0 = (uint32_t)(slot * STEP_BYTES) + roff[0], ab1 = (uint32_t)(slot * STEP_BYTES) + roff[1];
 #pragma unroll
@@ -726,7 +733,12 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
           constexpr int fn = f + NB;
           lds_read_frag(c[f % NB], ((fn >> 1) & 1) ? ab1 : ab0, (fn >> 2) * 4096 + (fn & 1) * 2048);
         }
+#if RR_WIDE8_SPREAD
+        if constexpr ((f & 3) == 1 && f < 16 && (f >> 3) < NQB) query_load_into(q[PN][f >> 3][(f >> 2) & 1], qoff[f >> 3], qsb, ((f >> 2) & 1) * 64);
+        if constexpr ((f & 3) == 1 && f >= 16) issue_piece(dkg, dslot, (f - 16) >> 2);
+#else
         if constexpr ((f & 7) == 3) issue_piece(dkg, dslot, f >> 3);
+#endif
       });
     } else {
 #pragma unroll
