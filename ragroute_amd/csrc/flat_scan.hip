@@ -34,6 +34,9 @@ namespace rr {
 // L2 = true ranks by  q.x - |x|^2/2  (descending == ascending squared L2 distance): the per-row |x|^2/2 of a tile is
 // one more 256-byte LDS-DMA piece (issued by wave 0, ahead of the tile-after-next's pieces so the in-order vmcnt wait of
 // the tile covers it) and the epilogue subtracts it before the filter.
+#ifndef RR_SCAN_STAGGER
+#define RR_SCAN_STAGGER 0
+#endif
 template <typename T, int D, bool DENSE, bool NT = false, bool L2 = false>
 __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   typedef typename Mfma<T>::frag frag;
@@ -158,6 +161,12 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
     }
     if (a.timeline) ++dbg_iter;
     __builtin_amdgcn_s_barrier();
+#if RR_SCAN_STAGGER
+    // the four waves leave the barrier together and share one address unit: start wave w one MFMA time (16 cycles) x w late so
+    // that their DMA instructions, which sit at the same places of the same code, do not arrive there together
+    if (wave & 1) asm volatile("s_nop 15" ::: "memory");
+    if (wave & 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
     int nslot = slot + INFL;
     if (nslot >= NS) nslot -= NS;
     uint32_t j2 = j + INFL * stride;
