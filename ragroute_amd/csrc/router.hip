@@ -340,6 +340,7 @@ size_t router_workspace_bytes(const rr_router_weights* w, int nq) {
   // the matrix-core form pays off for batches and for routers with several encoders or many sources (measured, 256 queries:
   // feb4rag 13 sources / 8 encoders and wikipedia 10 sources / 1 encoder faster, medrag 4 sources / 1 encoder not)
   if (nq < kRouterMfmaMinQueries || (w->n_models == 1 && w->n_sources < 8)) return 0;
+  if (fc1_chunks(w->d_max) > 64) return 0;   // router_head_kernel lists the live chunks of a tile with one wave ballot
   const size_t slots = (size_t)fc1_tiles(nq) * w->n_models * fc1_chunks(w->d_max);
   return slots * kFc1Q * 256 * sizeof(float) + ((slots + 255) / 256) * 256;
 }
