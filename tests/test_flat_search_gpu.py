@@ -296,3 +296,15 @@ def test_wide_rows_adversarial(gpu, d, nq):
     Dref, Iref = O.flat_search_ip(xb, xq, k)
     assert not np.isin(I, bad).any()
     assert np.array_equal(I, Iref) and np.array_equal(D, Dref)
+
+
+@pytest.mark.parametrize("d,n,nq,k", [(1024, 60_000, 200, 500), (2048, 40_000, 256, 100), (4096, 30_000, 256, 300), (1536, 50_000, 129, 1024)])
+def test_wide_rows_large_k(gpu, d, n, nq, k):
+    """Large k through the wide-row kernels (two waves per SIMD up to d = 2048, one above): candidate buffers of 2k entries per
+    lane, compactions inlined in the kernel, several chunks.  Integer data: ids and scores bit for bit."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(d + k)
+    xb, xq = int_data(rng, n, d), int_data(rng, nq, d)
+    D, I = _index(gpu, xb, d).search(xq, k)
+    Dr, Ir = O.flat_search_ip(xb, xq, k)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
