@@ -113,6 +113,7 @@ def build(force=False, verbose=False):
             if verbose and err:
                 print(err)
     open(stamp, "w").write(" ".join(flags))
-    check_isa(os.path.join(OBJ_DIR, "flat_scan_wide" + suffix + ".o"))
+    if not os.environ.get("RR_SKIP_ISA_CHECK"):   # diagnostic builds only
+        check_isa(os.path.join(OBJ_DIR, "flat_scan_wide" + suffix + ".o"))
     _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + [o for _, o, _ in jobs], "hipcc -shared")
     return lib_path

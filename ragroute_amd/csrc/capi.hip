@@ -115,7 +115,7 @@ Workspace carve(char* base, int k, int grid) {
   w.scratch = (uint64_t*)take((size_t)grid * 8 * cap * sizeof(uint64_t));  // up to 2 workgroups per CU x 4 waves
   w.dense = (float*)take((size_t)kQueriesPerBlock * kSampleRows * sizeof(float));
   w.cand = (uint64_t*)take((size_t)kQueriesPerBlock * grid * 4 * cap * sizeof(uint64_t));
-  w.xqs = take((size_t)kQueriesPerBlock * kMaxResidentDim * 2);  // the query block in MFMA-fragment order (prep kernel)
+  w.xqs = take((size_t)kQueriesPerBlock * kMaxResidentDim * 2);  // the query block in MFMA-fragment order (prep kernel): 256 x 768 or 128 x 1536 elements
   w.total = off;
   return w;
 }
@@ -207,10 +207,12 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
     a.xb = xb; a.xq = xq_b; a.thr = w.thr; a.cand = w.cand; a.cand_cnt = w.cand_cnt; a.scratch = w.scratch;
     a.dense = w.dense; a.n_rows = (uint32_t)n_rows; a.nq = (uint32_t)nqb; a.dense_ld = kSampleRows; a.cap = cap; a.k = k;
     a.half_sqnorm = half_sqnorm;
-    a.xqs = w.xqs;
+    // (per query block: launch_flat_scan picks the kernel from the block's own query count, e.g. the 44-query tail of a 300-query call)
+    const int bpw = dtype == kDtypeI8 ? 4 : scan_query_blocks_per_wave(dim, nqb, half_sqnorm != nullptr);
+    a.xqs = bpw ? w.xqs : nullptr;
 
     bool finalized = false;
-    RR_CHECK(launch_prep(s, xq_b, w.xqs, dim, st), "rr_flat_search/prep");
+    RR_CHECK(launch_prep(s, xq_b, w.xqs, dim, bpw, st), "rr_flat_search/prep");
     if (n_rows > 0 && n_rows <= kDenseMaxRows) {
       // tiny corpus: all scores, one exact selection
       a.tile_first = 0; a.tile_stride = 1; a.n_tiles = total_tiles;

@@ -281,17 +281,17 @@ __global__ __launch_bounds__(256, 1) void flat_scan16h_kernel(const ScanArgs a) 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 15, g = lane >> 4;
 
+  // (resident queries come from the fragment-order copy of the prep kernel, a.xqs: [wave][2 blocks][k slice][lane][8])
   frag q[2][KS2];
   {
-    const T* xq = (const T*)a.xq;
+    const T* xqs = (const T*)a.xqs;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-      const uint32_t qi = wave * 32 + qb * 16 + col;
-      const T* p = xq + (size_t)(qi < a.nq ? qi : a.nq - 1) * D + 8 * g;
+      const T* p = xqs + ((size_t)(wave * 2 + qb) * KS2 * 64 + lane) * 8;
 #pragma unroll
       for (int s2 = 0; s2 < KS2; ++s2) {
-        if (qb * KS2 + s2 < NAQ) agpr_load_frag(q[qb][s2], p + 32 * s2);
-        else q[qb][s2] = *(const frag*)(p + 32 * s2);
+        if (qb * KS2 + s2 < NAQ) agpr_load_frag(q[qb][s2], p + 512 * s2);
+        else q[qb][s2] = *(const frag*)(p + 512 * s2);
       }
     }
 #pragma unroll
@@ -500,6 +500,15 @@ int scan_queries_per_launch(int D, int nq) {
   read_variant_env();
   if (g_scan_variant == 3) return 256;
   return (half_resident_dim(D) && nq < g_wide_min_queries) ? 128 : 256;  // (an L2 search at these dims still works in 128-query blocks: each goes to the wide-row kernel)
+}
+
+// 16-query blocks each wave keeps resident in the kernel that will serve (D, nq, metric): 4 (d <= 768), 2 (768 < d <= 1536 and a
+// small inner-product batch), 0 = the wide-row kernels, which stream the row-major queries.  The prep kernel lays the queries out
+// accordingly (fragment order).
+int scan_query_blocks_per_wave(int D, int nq, bool l2) {
+  read_variant_env();
+  if (D <= kMaxResidentDim) return 4;
+  return (half_resident_dim(D) && nq < g_wide_min_queries && !l2) ? 2 : 0;
 }
 
 // candidate buffers per (workgroup, query) of the kernel that will serve this dim: the production kernels all use 4 lane quarters

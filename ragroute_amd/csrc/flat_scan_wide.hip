@@ -49,6 +49,10 @@ template <int N, typename F>
 __device__ __forceinline__ void vm_wait_tied8(F& r0, F& r1, F& r2, F& r3, F& r4, F& r5, F& r6, F& r7) {
   asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "n"(N) : "memory");
 }
+template <typename F>
+__device__ __forceinline__ void vm_drain_tied(F& r0, F& r1) {  // every vector-memory op has landed before r0 / r1 can be reused
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1)::"memory");
+}
 // DENSE launches (bootstrap sample, corpora <= 8192 rows) cover at most 256 tiles: with 8-tile groups only 32 workgroups would
 // have work and each would still walk the whole K loop (112 us at d = 4096), so they use one tile per group.
 template <typename T, bool DENSE, bool L2 = false>
@@ -261,9 +265,16 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_kernel(const ScanArgs a
 // it could insert the register copies that read a destination before its load has landed (the failure mode of "=v" loads
 // whose values are live around a back-edge).  wave_compact is inlined here: a call would spill the caller-saved part of
 // those buffers around it and restore stale copies over loads that landed meanwhile.
+// (the base goes through readfirstlane: it is uniform by construction, but should hipcc's divergence analysis ever think
+// otherwise it would hand the "s" operand a VGPR pair - seen in a diagnostic build - and the instruction would not assemble)
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const void*)(((uint64_t)hi << 32) | lo);
+}
 template <typename F>
 __device__ __forceinline__ void query_load_into(const F& dst, uint32_t lane_off, const void* sbase, int imm) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" ::"v"(dst), "v"(lane_off), "s"(sbase), "n"(imm) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" ::"v"(dst), "v"(lane_off), "s"(uniform_ptr(sbase)), "n"(imm) : "memory");
 }
 template <typename T> struct Mfma16FixedIn;
 #define RR_MFMA16FI(NAME, MNEMONIC, FRAG)                                                                            \
@@ -280,6 +291,12 @@ RR_MFMA16FI(__bf16, "v_mfma_f32_16x16x32_bf16", bf16x8)
 
 #ifndef RR_WIDE_SPREAD
 #define RR_WIDE_SPREAD 1   // measured at d = 4096, 2M rows, 256 queries: 0.496 vs 0.480 of the HBM peak (scan launches)
+#endif
+#ifndef RR_WIDE_VADDR
+#define RR_WIDE_VADDR 0
+#endif
+#ifndef RR_WIDE_DEBUG
+#define RR_WIDE_DEBUG 0
 #endif
 #ifndef RR_WIDE_ABL
 #define RR_WIDE_ABL 0   // development: timing-only ablations of the step (1 barrier, 2 query loads, 4 DMA, 8 LDS reads, 16 MFMA)
@@ -322,6 +339,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
   const size_t row_bytes = (size_t)D * 2;
   const char* dbase = (const char*)a.xb;   // uniform: first row of the DMA stream's group, + K offset
   uint32_t voff[NT];
+
   auto dma_new_group = [&](uint32_t grp) {
     if (grp >= n_groups) return;           // the stream runs ahead of the last group: it re-reads that one (valid memory, never used)
     const uint32_t row_base = (a.tile_first + grp * NT * a.tile_stride) * kTileRows;   // < n_rows: the group's first tile exists
@@ -336,9 +354,33 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
     }
   };
   auto issue_piece = [&](int kg, int slot, int t) {
+#if RR_WIDE_VADDR   // diagnostic: the 64-bit per-lane address form (global_load_lds v[lo:hi], off) instead of SGPR base + 32-bit lane offset
+    uint64_t b = (uint64_t)(dbase + (size_t)kg * 128);
+    asm volatile("" : "+v"(b));
+    const char* sb = (const char*)b;
+#else
     const char* sb = dbase + (size_t)kg * 128;
+#endif
+#if RR_WIDE_DEBUG   // diagnostic build: catch a DMA source address outside the corpus, record who computed it, read the first row instead
+    const char* pp = sb + voff[t];
+    {
+      const char* lo = (const char*)a.xb;
+      const char* hi = lo + (size_t)a.n_rows * row_bytes;
+      const bool bad = pp < lo || pp + 16 > hi;
+      const uint64_t bal = __builtin_amdgcn_ballot_w64(bad);
+      if (bal && a.timeline && lane == __builtin_ctzll(bal)) {
+        uint64_t* r = a.timeline + (size_t)(blockIdx.x * 4 + wave) * 8;   // last bad piece of this wave
+        r[0] = 0xBADull | ((uint64_t)t << 16) | ((uint64_t)kg << 24) | ((uint64_t)slot << 40) | ((uint64_t)lane << 48);
+        r[1] = voff[t]; r[2] = (uint64_t)dbase; r[3] = (uint64_t)pp; r[4] = bal; r[5] = (uint64_t)lo; r[6] = (uint64_t)hi; r[7] = n_groups;
+      }
+      if (bad) pp = lo + (lane & 7) * 16;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pp,
+                                     (__attribute__((address_space(3))) void*)(smem + slot * STEP_BYTES + t * 4096 + wave * 1024), 16, 0, 2);
+#else
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voff[t]),
                                      (__attribute__((address_space(3))) void*)(smem + slot * STEP_BYTES + t * 4096 + wave * 1024), 16, 0, 2);
+#endif
   };
 
   // query blocks of this wave that hold real queries (wave-uniform); a kernel instance serves NQB blocks per wave
@@ -469,9 +511,13 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
 #endif
 #if RR_WIDE_SPREAD
         if (NT == 8) {
+#if !(RR_WIDE_ABL & 2)
           if constexpr ((f & 1) == 1 && f < 16 && (f >> 2) < NQB)
             query_load_into(q[PN][f >> 2][(f >> 1) & 1], qoff[f >> 2], qsb, ((f >> 1) & 1) * 64);
+#endif
+#if !(RR_WIDE_ABL & 4)
           if constexpr ((f & 1) == 1 && f >= 16) issue_piece(dkg, dslot, (f - 16) >> 1);
+#endif
         } else {
           if (f == 0) load_queries(std::integral_constant<int, PN>{}, nkg);
           if ((f & 3) == 1) issue_piece(dkg, dslot, f >> 2);
@@ -538,7 +584,16 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
     }
     grp += gridDim.x;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+  // No LDS-DMA may outlive the workgroup - and no prefetched query load may outlive the LOOP: the sets of the steps that will
+  // never run are still landing in the q registers, which hipcc regards as free from here on.  It computed the addresses of the
+  // stores below in them BEFORE an untied wait (ALU work is not ordered by a "memory" clobber) and a late load then overwrote
+  // the address: wild stores, intermittently, and only where the buffer in flight at loop exit was one the tail reuses (the
+  // few-query kernel at d = 2048, KG mod 3 == 2).  The wait therefore names every q register as in/out: nothing of the tail
+  // can be placed in them before it has executed.
+  static_for<QB * NQB>([&](auto i) {
+    constexpr int b = decltype(i)::value / NQB, qb = decltype(i)::value % NQB;
+    vm_drain_tied(q[b][qb][0], q[b][qb][1]);
+  });
   if (!DENSE) {
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) a.cand_cnt[(wave * 64 + qb * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
@@ -794,7 +849,11 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
     }
     grp += gridDim.x;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // (the wait is tied to every q register: see the end of flat_scan_wide_pd_kernel)
+  static_for<QB * NQB>([&](auto i) {
+    constexpr int b = decltype(i)::value / NQB, qb = decltype(i)::value % NQB;
+    vm_drain_tied(q[b][qb][0], q[b][qb][1]);
+  });
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) a.cand_cnt[(wave * QPW + qb * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
 }

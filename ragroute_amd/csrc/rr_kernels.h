@@ -9,7 +9,7 @@ namespace rr {
 struct ScanArgs {
   const void* xb;       // [n_rows][D] f16/bf16 corpus (D = padded dim)
   const void* xq;       // [nq][D] queries, same dtype
-  const void* xqs;      // the same 256 queries in MFMA-fragment order (prep kernel): [wave 4][block 4][k slice D/32][lane 64][8 elements]
+  const void* xqs;      // the same queries in MFMA-fragment order (prep kernel): [wave 4][block 4 or 2][k slice D/32][lane 64][8 elements]
   const float* thr;     // [256] strict thresholds (filter mode)
   uint64_t* cand;       // [256][grid*2][cap] candidate keys (filter mode)
   uint32_t* cand_cnt;   // [256][grid*2]
@@ -28,6 +28,7 @@ hipError_t launch_flat_scan(const ScanArgs& a, int dtype, int D, bool dense, int
 int scan_padded_dim(int d);
 int scan_bufs_per_wg(int D, bool l2);
 int scan_queries_per_launch(int D, int nq);  // nq = queries of the whole call
+int scan_query_blocks_per_wave(int D, int nq, bool l2);  // 4 / 2: the kernel reads the fragment-order copy; 0: row-major queries
 
 // select.hip
 struct SelectArgs {
@@ -42,7 +43,7 @@ struct SelectArgs {
   int cap, k;
 };
 // init_state + copy of the query block into fragment order (xqs; nullptr or dim > 768: init only)
-hipError_t launch_prep(const SelectArgs& a, const void* xq, void* xqs, int dim, hipStream_t st);
+hipError_t launch_prep(const SelectArgs& a, const void* xq, void* xqs, int dim, int blocks_per_wave, hipStream_t st);
 hipError_t launch_dense_select(const SelectArgs& a, bool bootstrap, hipStream_t st);
 // fin != nullptr: this is the last compaction of an inner-product search, emit (D, I) directly (no finalize launch)
 struct FinalizeArgs { float* D; int64_t* I; int64_t id_offset; const uint8_t* mask; int64_t mask_stride; };

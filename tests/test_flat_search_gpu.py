@@ -308,3 +308,16 @@ def test_wide_rows_large_k(gpu, d, n, nq, k):
     D, I = _index(gpu, xb, d).search(xq, k)
     Dr, Ir = O.flat_search_ip(xb, xq, k)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
+@pytest.mark.parametrize("d,nq", [(1024, 300), (1280, 260), (1536, 385), (1024, 128), (896, 129)])
+def test_more_than_one_query_block_at_half_resident_widths(gpu, d, nq):
+    """768 < d <= 1536: a call is served in blocks of 256 queries; a block of up to 128 takes the query-resident kernel (which
+    reads the prep kernel's fragment-order copy), a fuller one the wide-row kernel (row-major queries) - e.g. 300 queries =
+    256 + 44.  Each block must get the layout its own kernel reads."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(d + nq)
+    xb, xq = int_data(rng, 20_000, d), int_data(rng, nq, d)
+    D, I = _index(gpu, xb, d).search(xq, 10)
+    Dr, Ir = O.flat_search_ip(xb, xq, 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
