@@ -74,6 +74,7 @@ def check_isa(obj_path):
             continue
         if current and re.search(r"\b(v_accvgpr_write|v_accvgpr_mov|scratch_load|scratch_store)", line):
             problems.append(f"{current}: {line.strip()}")
+    problems += check_prefetch_registers(dis)
     os.remove(co)
     if seen == 0:
         problems.append("no kernel named " + " / ".join(FIXED_AGPR_KERNELS) + " found in the device code")
@@ -81,6 +82,55 @@ def check_isa(obj_path):
         raise RuntimeError("ISA check of the fixed-AGPR kernels failed (the compiler used AGPRs or scratch of its own):\n  " +
                            "\n  ".join(problems[:40]))
     return seen
+
+
+# kernels whose query prefetch (inline-asm global_load_dwordx4 with an SGPR base) stays in flight across loop iterations
+PREFETCH_KERNELS = ("flat_scan_wide_pd_kernel", "flat_scan_wide8_kernel")
+_QLOAD = re.compile(r"^\s*global_load_dwordx4 v\[(\d+):(\d+)\], v\d+, s\[")
+_VDEST = re.compile(r"^\s*(?:v_(?!cmp|mfma|accvgpr_write)\w+|ds_read\w*|global_load\w*|buffer_load\w*)\s+v(?:(\d+)\b|\[(\d+):(\d+)\])")
+
+
+def check_prefetch_registers(dis):
+    """The prefetched query loads land asynchronously in registers the compiler only sees as asm operands.  Anything else
+    that writes one of those registers is safe only after the loop, behind an s_waitcnt vmcnt(0): a tail that computed store
+    addresses in them while the last prefetch was still landing produced wild stores (round 2, d = 2048, few queries)."""
+    problems, current, body = [], None, []
+
+    def finish():
+        if not current or not body:
+            return
+        loads = [(i, range(int(m.group(1)), int(m.group(2)) + 1)) for i, l in enumerate(body) for m in [_QLOAD.match(l)] if m]
+        if not loads:
+            problems.append(f"{current}: no asm query loads found (pattern out of date?)")
+            return
+        qregs = {r for _, rs in loads for r in rs}
+        first, last = loads[0][0], loads[-1][0]
+        for i, l in enumerate(body):
+            m = _VDEST.match(l)
+            if not m or i <= first or _QLOAD.match(l):
+                continue
+            regs = {int(m.group(1))} if m.group(1) else set(range(int(m.group(2)), int(m.group(3)) + 1))
+            if not regs & qregs:
+                continue
+            drained, j = False, i - 1          # a drain earlier in the same straight-line run (back to the previous branch)
+            while i > last and j > last and not re.match(r"^\s*(s_branch|s_cbranch|s_endpgm|s_setpc)", body[j]):
+                if re.match(r"^\s*s_waitcnt vmcnt\(0\)", body[j]):
+                    drained = True
+                    break
+                j -= 1
+            if not drained:
+                problems.append(f"{current}: query-prefetch register written while loads may be in flight: {l.strip()}")
+
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            finish()
+            current = m.group(1) if any(k in m.group(1) for k in PREFETCH_KERNELS) else None
+            body = []
+        elif current:
+            body.append(line.split("//")[0])
+    finish()
+    return problems
 
 
 def build(force=False, verbose=False):

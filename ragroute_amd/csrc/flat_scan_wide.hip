@@ -292,12 +292,6 @@ RR_MFMA16FI(__bf16, "v_mfma_f32_16x16x32_bf16", bf16x8)
 #ifndef RR_WIDE_SPREAD
 #define RR_WIDE_SPREAD 1   // measured at d = 4096, 2M rows, 256 queries: 0.496 vs 0.480 of the HBM peak (scan launches)
 #endif
-#ifndef RR_WIDE_VADDR
-#define RR_WIDE_VADDR 0
-#endif
-#ifndef RR_WIDE_DEBUG
-#define RR_WIDE_DEBUG 0
-#endif
 #ifndef RR_WIDE_ABL
 #define RR_WIDE_ABL 0   // development: timing-only ablations of the step (1 barrier, 2 query loads, 4 DMA, 8 LDS reads, 16 MFMA)
 #endif
@@ -354,33 +348,9 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
     }
   };
   auto issue_piece = [&](int kg, int slot, int t) {
-#if RR_WIDE_VADDR   // diagnostic: the 64-bit per-lane address form (global_load_lds v[lo:hi], off) instead of SGPR base + 32-bit lane offset
-    uint64_t b = (uint64_t)(dbase + (size_t)kg * 128);
-    asm volatile("" : "+v"(b));
-    const char* sb = (const char*)b;
-#else
     const char* sb = dbase + (size_t)kg * 128;
-#endif
-#if RR_WIDE_DEBUG   // diagnostic build: catch a DMA source address outside the corpus, record who computed it, read the first row instead
-    const char* pp = sb + voff[t];
-    {
-      const char* lo = (const char*)a.xb;
-      const char* hi = lo + (size_t)a.n_rows * row_bytes;
-      const bool bad = pp < lo || pp + 16 > hi;
-      const uint64_t bal = __builtin_amdgcn_ballot_w64(bad);
-      if (bal && a.timeline && lane == __builtin_ctzll(bal)) {
-        uint64_t* r = a.timeline + (size_t)(blockIdx.x * 4 + wave) * 8;   // last bad piece of this wave
-        r[0] = 0xBADull | ((uint64_t)t << 16) | ((uint64_t)kg << 24) | ((uint64_t)slot << 40) | ((uint64_t)lane << 48);
-        r[1] = voff[t]; r[2] = (uint64_t)dbase; r[3] = (uint64_t)pp; r[4] = bal; r[5] = (uint64_t)lo; r[6] = (uint64_t)hi; r[7] = n_groups;
-      }
-      if (bad) pp = lo + (lane & 7) * 16;
-    }
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pp,
-                                     (__attribute__((address_space(3))) void*)(smem + slot * STEP_BYTES + t * 4096 + wave * 1024), 16, 0, 2);
-#else
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voff[t]),
                                      (__attribute__((address_space(3))) void*)(smem + slot * STEP_BYTES + t * 4096 + wave * 1024), 16, 0, 2);
-#endif
   };
 
   // query blocks of this wave that hold real queries (wave-uniform); a kernel instance serves NQB blocks per wave

@@ -67,3 +67,22 @@ def test_product_never_imports_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".h")):
                 assert "oracle" not in open(os.path.join(dirpath, f)).read().lower(), f
+
+
+def test_isa_check_flags_a_prefetch_register_reused_before_the_drain():
+    """The build refuses a wide-row kernel whose tail writes a query-prefetch register before s_waitcnt vmcnt(0)
+    (the cause of intermittent wild stores in round 2), and accepts the same tail behind the wait."""
+    from ragroute_amd import _build
+    head = ["0000000000001000 <_ZN2rr24flat_scan_wide_pd_kernelIfLb0ELb0ELi1ELi2EEEvNS_8ScanArgsEi>:",
+            "\tglobal_load_dwordx4 v[2:5], v41, s[4:5]",
+            "\tglobal_load_dwordx4 v[6:9], v41, s[4:5] offset:64",
+            "\tv_mfma_f32_16x16x32_f16 a[0:3], v[60:63], v[2:5], a[0:3]",
+            "\ts_cbranch_scc1 65000"]
+    bad = head + ["\tv_add_u32_e32 v2, v1, v40", "\ts_waitcnt vmcnt(0)", "\tglobal_store_dword v[2:3], v54, off", "\ts_endpgm"]
+    good = head + ["\ts_waitcnt vmcnt(0)", "\tv_add_u32_e32 v2, v1, v40", "\tglobal_store_dword v[2:3], v54, off", "\ts_endpgm"]
+    in_loop = head[:3] + ["\tv_mov_b32_e32 v6, v10"] + head[3:] + ["\ts_endpgm"]
+    assert len(_build.check_prefetch_registers("\n".join(bad))) == 1
+    assert _build.check_prefetch_registers("\n".join(good)) == []
+    assert len(_build.check_prefetch_registers("\n".join(in_loop))) == 1
+    other = "\n".join(bad).replace("flat_scan_wide_pd_kernel", "flat_scan16_kernel__")
+    assert _build.check_prefetch_registers(other) == []
