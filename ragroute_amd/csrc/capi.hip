@@ -115,7 +115,7 @@ Workspace carve(char* base, int k, int grid) {
   w.scratch = (uint64_t*)take((size_t)grid * 8 * cap * sizeof(uint64_t));  // up to 2 workgroups per CU x 4 waves
   w.dense = (float*)take((size_t)kQueriesPerBlock * kSampleRows * sizeof(float));
   w.cand = (uint64_t*)take((size_t)kQueriesPerBlock * grid * 4 * cap * sizeof(uint64_t));
-  w.xqs = take((size_t)kQueriesPerBlock * kMaxResidentDim * 2);  // the query block in MFMA-fragment order (prep kernel): 256 x 768 or 128 x 1536 elements
+  w.xqs = take((size_t)kQueriesPerBlock * kMaxDim * 2);  // the query block in MFMA-fragment order (prep kernel): 256 queries x the padded dim
   w.total = off;
   return w;
 }

@@ -508,7 +508,8 @@ int scan_queries_per_launch(int D, int nq) {
 int scan_query_blocks_per_wave(int D, int nq, bool l2) {
   read_variant_env();
   if (D <= kMaxResidentDim) return 4;
-  return (half_resident_dim(D) && nq < g_wide_min_queries && !l2) ? 2 : 0;
+  if (half_resident_dim(D) && nq < g_wide_min_queries && !l2) return 2;
+  return RR_WIDE_QFRAG ? 4 : 0;   // wide-row kernels: the 16 blocks of a 256-query pass, same [block][k slice][lane][8] order
 }
 
 // candidate buffers per (workgroup, query) of the kernel that will serve this dim: the production kernels all use 4 lane quarters

@@ -292,6 +292,15 @@ RR_MFMA16FI(__bf16, "v_mfma_f32_16x16x32_bf16", bf16x8)
 #ifndef RR_WIDE_SPREAD
 #define RR_WIDE_SPREAD 1   // measured at d = 4096, 2M rows, 256 queries: 0.496 vs 0.480 of the HBM peak (scan launches)
 #endif
+#if RR_WIDE_QFRAG
+#define RR_WIDE_QBASE(a) ((const char*)(a).xqs)
+#define RR_WIDE_QSTEP 2048     // bytes per 64-wide K step: two 32-wide k slices of 64 lanes x 16 B
+#define RR_WIDE_QPAR 1024
+#else
+#define RR_WIDE_QBASE(a) ((const char*)(a).xq)
+#define RR_WIDE_QSTEP 128
+#define RR_WIDE_QPAR 64
+#endif
 #ifndef RR_WIDE_ABL
 #define RR_WIDE_ABL 0   // development: timing-only ablations of the step (1 barrier, 2 query loads, 4 DMA, 8 LDS reads, 16 MFMA)
 #endif
@@ -358,8 +367,12 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
   uint32_t qoff[NQB];
 #pragma unroll
   for (int qb = 0; qb < NQB; ++qb) {
+#if RR_WIDE_QFRAG   // [16-query block wave*4+qb][k slice][lane][8]: slots past nq repeat the last query (prep_kernel)
+    qoff[qb] = (uint32_t)(wave * 4 + qb) * (uint32_t)(D * 32) + 16 * lane;
+#else
     const uint32_t qi = wave * 64 + qb * 16 + col;
     qoff[qb] = (qi < a.nq ? qi : a.nq - 1) * (uint32_t)(D * 2) + 16 * g;
+#endif
   }
   LaneState4 st;
   const uint32_t nbuf = gridDim.x * 4;
@@ -386,11 +399,11 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
     }
   auto load_queries = [&](auto buf_tag, int kg) {
     constexpr int B = decltype(buf_tag)::value;
-    const char* sb = (const char*)a.xq + (size_t)kg * 128;
+    const char* sb = RR_WIDE_QBASE(a) + (size_t)kg * RR_WIDE_QSTEP;
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
       query_load_into(q[B][qb][0], qoff[qb], sb, 0);
-      query_load_into(q[B][qb][1], qoff[qb], sb, 64);
+      query_load_into(q[B][qb][1], qoff[qb], sb, RR_WIDE_QPAR);
     }
   };
 
@@ -447,7 +460,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
       // step sit 2 fragments apart in the MFMA stream (queries in the first half, DMA in the second: same queue order).
       if (wave & 1) asm volatile("s_nop 15" ::: "memory");
       if (wave & 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-      const char* qsb = (const char*)a.xq + (size_t)nkg * 128;
+      const char* qsb = RR_WIDE_QBASE(a) + (size_t)nkg * RR_WIDE_QSTEP;
 #elif !(RR_WIDE_ABL & 2)
       load_queries(std::integral_constant<int, PN>{}, nkg);
 #endif
@@ -483,7 +496,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
         if (NT == 8) {
 #if !(RR_WIDE_ABL & 2)
           if constexpr ((f & 1) == 1 && f < 16 && (f >> 2) < NQB)
-            query_load_into(q[PN][f >> 2][(f >> 1) & 1], qoff[f >> 2], qsb, ((f >> 1) & 1) * 64);
+            query_load_into(q[PN][f >> 2][(f >> 1) & 1], qoff[f >> 2], qsb, ((f >> 1) & 1) * RR_WIDE_QPAR);
 #endif
 #if !(RR_WIDE_ABL & 4)
           if constexpr ((f & 1) == 1 && f >= 16) issue_piece(dkg, dslot, (f - 16) >> 1);
@@ -666,8 +679,12 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
   uint32_t qoff[NQB];
 #pragma unroll
   for (int qb = 0; qb < NQB; ++qb) {
+#if RR_WIDE_QFRAG
+    qoff[qb] = (uint32_t)(wave * 2 + qb) * (uint32_t)(D * 32) + 16 * lane;
+#else
     const uint32_t qi = wave * QPW + qb * 16 + col;
     qoff[qb] = (qi < a.nq ? qi : a.nq - 1) * (uint32_t)(D * 2) + 16 * g;
+#endif
   }
   LaneState4 st;
   const uint32_t nbuf = gridDim.x * 4;
@@ -693,11 +710,11 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
     }
   auto load_queries = [&](auto buf_tag, int kg) {
     constexpr int B = decltype(buf_tag)::value;
-    const char* sb = (const char*)a.xq + (size_t)kg * 128;
+    const char* sb = RR_WIDE_QBASE(a) + (size_t)kg * RR_WIDE_QSTEP;
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
       query_load_into(q[B][qb][0], qoff[qb], sb, 0);
-      query_load_into(q[B][qb][1], qoff[qb], sb, 64);
+      query_load_into(q[B][qb][1], qoff[qb], sb, RR_WIDE_QPAR);
     }
   };
 
@@ -737,7 +754,7 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
       int nkg = kg + PD;
       if (nkg >= KG) nkg -= KG;
 #if RR_WIDE8_SPREAD
-      const char* qsb = (const char*)a.xq + (size_t)nkg * 128;   // query loads go into the first half of the MFMA stream, 4 fragments apart
+      const char* qsb = RR_WIDE_QBASE(a) + (size_t)nkg * RR_WIDE_QSTEP;   // query loads go into the first half of the MFMA stream, 4 fragments apart
 #else
       load_queries(std::integral_constant<int, PN>{}, nkg);
 #endif
@@ -759,7 +776,7 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
           lds_read_frag(c[f % NB], ((fn >> 1) & 1) ? ab1 : ab0, (fn >> 2) * 4096 + (fn & 1) * 2048);
         }
 #if RR_WIDE8_SPREAD
-        if constexpr ((f & 3) == 1 && f < 16 && (f >> 3) < NQB) query_load_into(q[PN][f >> 3][(f >> 2) & 1], qoff[f >> 3], qsb, ((f >> 2) & 1) * 64);
+        if constexpr ((f & 3) == 1 && f < 16 && (f >> 3) < NQB) query_load_into(q[PN][f >> 3][(f >> 2) & 1], qoff[f >> 3], qsb, ((f >> 2) & 1) * RR_WIDE_QPAR);
         if constexpr ((f & 3) == 1 && f >= 16) issue_piece(dkg, dslot, (f - 16) >> 2);
 #else
         if constexpr ((f & 7) == 3) issue_piece(dkg, dslot, f >> 3);

@@ -9,7 +9,7 @@ namespace rr {
 struct ScanArgs {
   const void* xb;       // [n_rows][D] f16/bf16 corpus (D = padded dim)
   const void* xq;       // [nq][D] queries, same dtype
-  const void* xqs;      // the same queries in MFMA-fragment order (prep kernel): [wave 4][block 4 or 2][k slice D/32][lane 64][8 elements]
+  const void* xqs;      // the same queries in MFMA-fragment order (prep kernel): [wave 4][block 4 or 2][k slice D/32][lane 64][8 elements] (wide rows: 16 blocks)
   const float* thr;     // [256] strict thresholds (filter mode)
   uint64_t* cand;       // [256][grid*2][cap] candidate keys (filter mode)
   uint32_t* cand_cnt;   // [256][grid*2]
@@ -42,7 +42,7 @@ struct SelectArgs {
   uint32_t nbuf, list_ld;
   int cap, k;
 };
-// init_state + copy of the query block into fragment order (xqs; nullptr or dim > 768: init only)
+// init_state + copy of the query block into fragment order (xqs; nullptr or blocks_per_wave == 0: init only)
 hipError_t launch_prep(const SelectArgs& a, const void* xq, void* xqs, int dim, int blocks_per_wave, hipStream_t st);
 hipError_t launch_dense_select(const SelectArgs& a, bool bootstrap, hipStream_t st);
 // fin != nullptr: this is the last compaction of an inner-product search, emit (D, I) directly (no finalize launch)

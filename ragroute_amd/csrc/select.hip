@@ -24,7 +24,7 @@ __device__ __forceinline__ float next_below(float x) {
 // kernels' waves load their MFMA B fragments: [wave][16-query block (4 per wave at d <= 768, 2 at 768 < d <= 1536)][32-wide k slice][lane][8 elements], so that each
 // of the 96 loads of a wave (d = 768) is one contiguous KiB instead of 16 rows x 64 B.  (The row-major loads cost ~16 us of
 // every scan launch: 5 launches per search.)  Slots past nq repeat the last query, as the kernel's clamped loads did.
-__global__ __launch_bounds__(256) void prep_kernel(SelectArgs a, const uint4* __restrict__ xq, uint4* __restrict__ xqs, int dim, int bpw) {
+__global__ __launch_bounds__(256) void prep_kernel(SelectArgs a, const uint4* __restrict__ xq, uint4* __restrict__ xqs, int dim, int n_blocks) {
   if (blockIdx.x == 0) {
     const uint32_t q = threadIdx.x;
     a.list_cnt[q] = 0;
@@ -32,9 +32,9 @@ __global__ __launch_bounds__(256) void prep_kernel(SelectArgs a, const uint4* __
   }
   if (!xqs) return;
   const int ks2 = dim >> 5;                       // 32-wide k slices
-  const uint32_t total = 4u * bpw * ks2 * 64u;     // 16-byte chunks: 4 waves x bpw blocks x ks2 x 64 lanes
+  const uint32_t total = (uint32_t)n_blocks * ks2 * 64u;   // 16-byte chunks: 16-query blocks x ks2 x 64 lanes
   for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < total; c += gridDim.x * blockDim.x) {
-    const uint32_t lane = c & 63, s2 = (c >> 6) % ks2, wb = (c >> 6) / ks2;   // wb = wave * bpw + block: queries 16 wb .. +15
+    const uint32_t lane = c & 63, s2 = (c >> 6) % ks2, wb = (c >> 6) / ks2;   // wb = wave * blocks per wave + block: queries 16 wb .. +15
     const uint32_t col = lane & 15, g = lane >> 4;
     uint32_t qi = wb * 16 + col;
     qi = qi < a.nq ? qi : a.nq - 1;
@@ -328,8 +328,10 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const float* Din, cons
 
 hipError_t launch_prep(const SelectArgs& a, const void* xq, void* xqs, int dim, int blocks_per_wave, hipStream_t st) {
   const bool swz = xqs && blocks_per_wave > 0 && dim % 32 == 0;
-  const int blocks = swz ? (4 * blocks_per_wave * (dim / 32) * 64 + 255) / 256 : 1;
-  hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, st, a, (const uint4*)xq, swz ? (uint4*)xqs : nullptr, dim, blocks_per_wave);
+  // wide rows, at most 16 queries: the few-query kernels read block 0 only (the reference's call shape is one query)
+  const int n_blocks = (dim > 2 * kMaxResidentDim && a.nq <= 16) ? 1 : 4 * blocks_per_wave;
+  const int blocks = swz ? (n_blocks * (dim / 32) * 64 + 255) / 256 : 1;
+  hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, st, a, (const uint4*)xq, swz ? (uint4*)xqs : nullptr, dim, n_blocks);
   return hipGetLastError();
 }
 hipError_t launch_dense_select(const SelectArgs& a, bool bootstrap, hipStream_t st) {
