@@ -12,16 +12,20 @@ ROWS = [1, 31, 32, 33, 255, 256, 257, 1000, 8191, 8192, 8193, 8224, 10_000, 16_3
 KS = [1, 5, 10, 32, 33, 100, 128, 300]
 
 
-def cases(seed, count, max_work=6e9):
-    """-> list of dicts; work = n * d * nq (the oracle's f64 dot products) is bounded so a case checks in a second or two."""
+ROWS_BIG = [70_000, 131_072, 300_000, 524_288, 1_000_000, 2_000_000]   # several chunks of the geometric schedule
+
+
+def cases(seed, count, max_work=6e9, big=False):
+    """-> list of dicts; work = n * d * nq (the oracle's f64 dot products) is bounded so a case checks in a second or two.
+    big: corpora of 70 K ... 2 M rows (bootstrap + 2 ... 4 chunk launches + compactions) with correspondingly few queries."""
     rng = np.random.default_rng(seed)
     out = []
     while len(out) < count:
         d = int(rng.choice(DIMS))
-        n = int(rng.choice(ROWS)) + int(rng.integers(0, 3))
+        n = int(rng.choice(ROWS_BIG if big else ROWS)) + int(rng.integers(0, 3))
         nq = int(rng.choice(QUERIES))
         k = int(rng.choice(KS))
-        if n * d * nq > max_work:
+        if n * d * nq > max_work or n * d > 1.5e9:   # (host-side generation of the corpus stays in seconds)
             continue
         out.append({"d": d, "n": n, "nq": nq, "k": k, "dtype": "fp16" if rng.integers(0, 2) else "bf16",
                     "metric": "l2" if rng.integers(0, 4) == 0 else "ip", "seed": int(rng.integers(0, 2 ** 31))})

@@ -11,3 +11,9 @@ pytestmark = pytest.mark.gpu
 def test_seeded_fuzz_sample(gpu):
     failed = [c for c in cases(20261004, 150) if not run_case(c, gpu)]
     assert not failed, failed
+
+
+def test_seeded_fuzz_sample_large_corpora(gpu):
+    """The same on 70 K ... 2 M-row corpora: bootstrap sample, 2 ... 4 chunk launches and their compactions at every width class."""
+    failed = [c for c in cases(20261005, 16, max_work=3e10, big=True) if not run_case(c, gpu)]
+    assert not failed, failed

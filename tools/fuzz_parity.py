@@ -1,6 +1,6 @@
 """GPU: tests/fuzz_cases.py for COUNT cases from SEED (development; the bounded sample is tests/test_fuzz_gpu.py).
 
-    python tools/fuzz_parity.py [SEED] [COUNT]
+    python tools/fuzz_parity.py [SEED] [COUNT] [big]
 
 Prints every case before it runs (so a fault names its case) and a summary line."""
 import json
@@ -19,7 +19,8 @@ def main():
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     dev = torch.device("cuda:0")
     bad, t0 = [], time.time()
-    for i, c in enumerate(cases(seed, count)):
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"
+    for i, c in enumerate(cases(seed, count, max_work=3e10 if big else 6e9, big=big)):
         print(i, json.dumps(c), flush=True)
         if not run_case(c, dev):
             bad.append(c)
