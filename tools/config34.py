@@ -1,0 +1,115 @@
+"""BASELINE configs 3 and 4 at their real corpus SHAPES on one MI355X (synthetic embeddings, resident in HBM).
+
+    python tools/config34.py medrag|feb4rag [batches]
+
+  medrag   (config 3: "medrag 4 corpora on 1 GPU + router MLP forward, query batch=256"): pubmed / statpearls / textbooks /
+           wikipedia at MedRAG's snippet counts, 768 wide (config.py:28, 45), k = 32, router over 4 sources.
+  feb4rag  (config 4's work, whole federation on one GPU instead of 2 sources per GPU on 8): the 13 BEIR corpora at their
+           document counts, each as wide as its encoder (config.py:32-46: 768 / 1024 / 4096), k = 10, router over 13 sources
+           and 8 encoders, every source searched with its own embedding (http_server.py:198-209), merge over 13 k.
+
+One step = router MLP -> per source: query conversion + exact top-k with the route mask folded in -> merge; prints one JSON
+line: ms per batch (one HIP-event pair per batch, median), queries/s, corpus bytes / time against the 8 TB/s HBM peak, and
+the per-source search times (each source alone, same events)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from ragroute_amd import config as C
+from ragroute_amd.flat_index import FlatIndex
+from ragroute_amd.pipeline import RetrievalPipeline
+from ragroute_amd.router import CorpusRoutingNN, FoldedRouter
+
+ROWS = {   # MedRAG snippet counts (Xiong et al. 2024, table 1) and BEIR document counts (Thakur et al. 2021, table 1)
+    "medrag": {"pubmed": 23_900_000, "statpearls": 301_200, "textbooks": 125_800, "wikipedia": 29_900_000},
+    "feb4rag": {"msmarco": 8_841_823, "trec-covid": 171_332, "nfcorpus": 3_633, "scidocs": 25_657, "nq": 2_681_468,
+                "hotpotqa": 5_233_329, "fiqa": 57_638, "arguana": 8_674, "webis-touche2020": 382_545, "dbpedia-entity": 4_635_922,
+                "fever": 5_416_568, "climate-fever": 5_416_593, "scifact": 5_183},
+}
+WIDTH = {"e5-large": 1024, "SGPT-5.8B-weightedmean-msmarco-specb-bitfit": 4096, "UAE-Large-V1": 1024, "all-mpnet-base-v2": 768,
+         "multilingual-e5-large": 1024, "ember-v1": 1024, "e5-base": 768, "gte-base": 768, "ncbi/MedCPT-Query-Encoder": 768}
+
+
+def make(n, d, dim, seed, dev):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    xb = torch.zeros((n, dim), dtype=torch.float16, device=dev)
+    for s in range(0, n, 1 << 20):
+        e = min(n, s + (1 << 20))
+        x = torch.randn((e - s, d), generator=g, device=dev)
+        xb[s:e, :d] = (x / x.norm(dim=1, keepdim=True)).half()
+    return xb
+
+
+def main():
+    dataset = sys.argv[1] if len(sys.argv) > 1 else "medrag"
+    batches = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    dev = torch.device("cuda:0")
+    sources = C.DATA_SOURCES[dataset]
+    model_of = {s: C.EMBEDDING_MODELS_PER_DATA_SOURCE[dataset][s][0] for s in sources}
+    models = sorted(set(model_of.values()))
+    d_max, k, B = C.EMBEDDING_MAX_LENGTH[dataset], C.K[dataset], 256
+    shards, cents, total_bytes = [], [], 0
+    for i, s in enumerate(sources):
+        d = WIDTH[model_of[s]]
+        idx = FlatIndex(d, device=dev)
+        idx.adopt(make(ROWS[dataset][s], d, idx.dim, 1234 + i, dev))
+        shards.append(idx)
+        total_bytes += idx.ntotal * idx.dim * 2
+        c = np.zeros(d_max, np.float32)
+        c[:d] = idx.centroid().cpu().numpy()[:d]
+        cents.append(c)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321)
+    emb = {}
+    for m in models:
+        x = torch.randn((B, WIDTH[m]), generator=g, device=dev)
+        emb[m] = x / x.norm(dim=1, keepdim=True)
+    xq_models = torch.zeros((B, len(models), d_max), device=dev)
+    for j, m in enumerate(models):
+        xq_models[:, j, : WIDTH[m]] = emb[m]
+    onehot = [C.FEB4RAG_SOURCE_TO_ID[s] for s in sources] if dataset == "feb4rag" else [C.MEDRAG_SOURCE_TO_ID[s] for s in sources]
+    net = CorpusRoutingNN(C.ROUTER_INPUT_DIMENSION[dataset], seed=0)
+    router = FoldedRouter.fold(net.state_dict(), np.stack(cents), onehot, len(sources), d_max, [models.index(model_of[s]) for s in sources],
+                               C.ROUTER_THRESHOLD[dataset], device=dev)
+    pipe = RetrievalPipeline(shards, list(range(len(sources))), router=router, slots=len(sources))
+    xq = {i: emb[model_of[s]] for i, s in enumerate(sources)}
+
+    def step():
+        return pipe.search(xq, k, xq_models=xq_models)
+
+    def timed(fn, n):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return sorted(a.elapsed_time(b) for a, b in evs)
+
+    for _ in range(3):
+        D, I = step()
+    ms = timed(step, batches)
+    med = ms[len(ms) // 2]
+    _, mask = router.run(xq_models)
+    per_source = {}
+    for i, s in enumerate(sources):
+        q = shards[i].prepare_queries(xq[i])
+        t = timed(lambda: shards[i].search_prepared(q, k), 5)
+        per_source[s] = {"rows": shards[i].ntotal, "dim": shards[i].dim, "ms": round(t[2], 4),
+                         "frac_of_8TBps": round(shards[i].ntotal * shards[i].dim * 2 / (t[2] * 1e-3) / 8e12, 4)}
+    print(json.dumps({
+        "config": f"{dataset}: {len(sources)} sources at their real row counts and encoder widths on 1 GPU, B={B}, k={k}, router + per-source exact top-k + merge",
+        "rows_total": int(sum(ROWS[dataset].values())), "corpus_GB": round(total_bytes / 1e9, 2), "median_ms_per_batch": round(med, 3),
+        "p10_ms": round(ms[len(ms) // 10], 3), "p90_ms": round(ms[(len(ms) * 9) // 10], 3), "queries_per_s": round(B / med * 1e3, 1),
+        "corpus_GBps": round(total_bytes / 1e9 / (med * 1e-3), 1), "frac_of_8TBps": round(total_bytes / (med * 1e-3) / 8e12, 4),
+        "sources_selected_per_query": round(float(mask.float().sum(1).mean()), 2),
+        "per_source_alone": per_source}))
+
+
+if __name__ == "__main__":
+    main()
