@@ -86,7 +86,7 @@ def main():
         fetch = counters(f)
         write = counters(os.path.join(SRC, f"wide_write_{tag}", "t_counter_collection.csv"))
         l2 = counters(os.path.join(SRC, f"wide_l2_{tag}", "t_counter_collection.csv"))
-        searches = 9   # shape_bench.py ... 4: 5 warm-up + 4 timed searches
+        searches = 13  # shape_bench.py ... 4: 5 warm-up + 4 searches with per-search events + 4 back to back
         entry = {"kernel": max(fetch.values(), key=lambda d: d["FETCH_SIZE"])["kernel"],
                  "scan_launches_profiled": len(fetch),
                  "hbm_fetch_bytes_per_search_corrected": sum(d["FETCH_SIZE"] for d in fetch.values()) * 1024 * 2 / searches,
@@ -103,7 +103,7 @@ def main():
     if wide:
         json.dump(wide, open(os.path.join(DST, "wide_pmc_summary.json"), "w"), indent=1)
 
-    print("| shape | scan launches | whole search |\n|---|---|---|")
+    print("| shape | scan launches | whole search (event pair per search) | back to back |\n|---|---|---|---|")
     b = last_json(os.path.join(DST, "bench_n1.json"))
     r = b["roofline"]
     print(f"| 10M x 768, 256 queries (bench.py) | {r['achieved'] / 1000:.2f} TB/s = {r['frac']:.3f} | {b['ms_per_step']:.2f} ms, {r['end_to_end_frac']:.3f} |")
@@ -113,7 +113,8 @@ def main():
             continue
         j = last_json(p)
         r = j["roofline"]
-        print(f"| {tag} | {r['achieved'] / 1000:.2f} TB/s = {r['frac']:.3f} | {j['median_ms']:.3f} ms, {j.get('end_to_end_frac_of_8TBps')} |")
+        print(f"| {tag} | {r['achieved'] / 1000:.2f} TB/s = {r['frac']:.3f} | {j['median_ms']:.3f} ms, {j.get('end_to_end_frac_of_8TBps')} | "
+              f"{j.get('back_to_back_ms')} ms, {j.get('back_to_back_frac_of_8TBps')} |")
     c5 = os.path.join(DST, "config5_80M_bf16_k100.json")
     if os.path.exists(c5):
         j = last_json(c5)
