@@ -617,6 +617,9 @@ __device__ __forceinline__ f32x4 read_acc_fixed128() {
 #ifndef RR_WIDE8_SPREAD
 #define RR_WIDE8_SPREAD 0
 #endif
+#ifndef RR_WIDE8_ABL
+#define RR_WIDE8_ABL 0   // development, timing only (wrong results): 8 = every second LDS fragment read skipped, 32 = every query load
+#endif                   // issued twice, 64 = nothing (baseline with the insertion path shut, as the others have it)
 #ifndef RR_WIDE8_RING
 #define RR_WIDE8_RING 8   // A fragments in flight from LDS per wave
 #endif
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
   for (int qb = 0; qb < 4; ++qb) {
     const uint32_t qi = wave * QPW + (qb & 1) * 16 + col;
     st.thr[qb] = qb < 2 ? a.thr[qi] : 0.f;
-#if RR_WIDE_ABL
+#if RR_WIDE_ABL || RR_WIDE8_ABL
     st.thr[qb] = __builtin_inff();
 #endif
     st.cnt[qb] = 0;
@@ -757,11 +760,15 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
       const char* qsb = RR_WIDE_QBASE(a) + (size_t)nkg * RR_WIDE_QSTEP;   // query loads go into the first half of the MFMA stream, 4 fragments apart
 #else
       load_queries(std::integral_constant<int, PN>{}, nkg);
+#if RR_WIDE8_ABL & 32
+      load_queries(std::integral_constant<int, PN>{}, nkg);
+#endif
 #endif
       frag c[NB];
       const uint32_t ab0 = (uint32_t)(slot * STEP_BYTES) + roff[0], ab1 = (uint32_t)(slot * STEP_BYTES) + roff[1];
 #pragma unroll
-      for (int f = 0; f < NB; ++f) lds_read_frag(c[f], ((f >> 1) & 1) ? ab1 : ab0, (f >> 2) * 4096 + (f & 1) * 2048);
+      for (int f = 0; f < NB; ++f)
+        if (!(RR_WIDE8_ABL & 8) || !(f & 1)) lds_read_frag(c[f], ((f >> 1) & 1) ? ab1 : ab0, (f >> 2) * 4096 + (f & 1) * 2048);
       static_for<NF>([&](auto fi) {
         constexpr int f = decltype(fi)::value;
         constexpr int t = f >> 2, par = (f >> 1) & 1, rb = f & 1;
@@ -771,7 +778,7 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
           constexpr int qb = decltype(qi)::value;
           Mfma16Fixed128<T>::template run<8 * (2 * t + rb) + 4 * qb, FIRST && par == 0>(c[f % NB], q[P][qb][par]);
         });
-        if constexpr (f + NB < NF) {
+        if constexpr (f + NB < NF && (!(RR_WIDE8_ABL & 8) || !(f & 1))) {
           constexpr int fn = f + NB;
           lds_read_frag(c[f % NB], ((fn >> 1) & 1) ? ab1 : ab0, (fn >> 2) * 4096 + (fn & 1) * 2048);
         }
