@@ -234,9 +234,10 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
       uint64_t begin = 0;
       double endf = (double)n_sample_tiles * growth;  // in tiles
       while (begin < total_tiles) {
-        uint64_t end = (uint64_t)(endf + 0.5);
+        uint64_t end = ((uint64_t)(endf + 0.5) + 7) & ~7ull;   // whole 256-row groups: the wide-row kernels' K order is a function of the global group (flat_scan_wide.hip)
         if (end > total_tiles || (double)total_tiles < endf * 1.25) end = total_tiles;  // no sliver of a last chunk
-        if (end <= begin) end = begin + 1;
+        if (end <= begin) end = begin + 8;
+        if (end > total_tiles) end = total_tiles;
         a.tile_first = (uint32_t)begin; a.tile_stride = 1; a.n_tiles = (uint32_t)(end - begin);
         a.timeline = getenv("RR_SCAN_TIMELINE") ? (uint64_t*)w.dense : nullptr;  // the dense buffer is idle during chunk scans
         RR_CHECK(profiled_scan(a, dtype, dim, false, grid, st), "rr_flat_search/scan");

@@ -49,6 +49,27 @@ template <int N, typename F>
 __device__ __forceinline__ void vm_wait_tied8(F& r0, F& r1, F& r2, F& r3, F& r4, F& r5, F& r6, F& r7) {
   asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "n"(N) : "memory");
 }
+// K rotation (rows wider than 1536 elements).  Every K step of a group reads a 128-byte column slab of 256 rows; with a row pitch
+// of 4 or 8 KiB (d = 2048, 4096) those 256 addresses fall on a handful of HBM channels, and workgroups that walk the K steps in
+// the same order keep hitting the same ones: a single query streamed 2M x 2048 at 0.70 of the HBM peak against 0.84 at d = 1792.
+// So the 256-row group m (global: first tile / 8) starts its K loop at column (5 m) mod KG - rows and queries alike, the dot
+// product only changes its summation order.  The order is a function of the ROW GROUP alone (chunk boundaries are multiples of 8
+// tiles, capi.hip), so a row scores bit-identically in the sample launch, in whichever chunk launch it falls and in every
+// wide-row kernel.  Measured: one query 0.70 -> 0.83 (d = 2048) and 0.71 -> 0.855 (d = 4096), 64 queries 0.66 -> 0.73 (d = 4096); 256
+// queries unchanged (compute-bound).
+#ifndef RR_WIDE_KROT
+#define RR_WIDE_KROT 5   // 0: every group starts at column 0 (A/B)
+#endif
+__device__ __forceinline__ int wide_group_rotation(const ScanArgs& a, uint32_t grp, int tiles_per_group, int KG) {
+  // only where the row pitch is a multiple of 2 KiB (d = 2048, 3072, 4096): other pitches spread over the channels by themselves
+  // (d = 1792: one query 0.845 without, 0.80 with), at d = 8192 the rotated query block (4 MB) no longer fits an XCD's L2 (256
+  // queries -2.9 %), and d <= 1536 is also served by the half-resident kernel, which has no rotation
+  if (!RR_WIDE_KROT || KG <= 24 || KG > 64 || (KG & 15)) return 0;
+  const uint32_t m = (a.tile_first + grp * (uint32_t)tiles_per_group * a.tile_stride) >> 3;
+  return (int)((m * (uint32_t)RR_WIDE_KROT) % (uint32_t)KG);
+}
+__device__ __forceinline__ int wide_rotated(int kg, int rot, int KG) { return kg + rot >= KG ? kg + rot - KG : kg + rot; }
+
 template <typename F>
 __device__ __forceinline__ void vm_drain_tied(F& r0, F& r1) {  // every vector-memory op has landed before r0 / r1 can be reused
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1)::"memory");
@@ -84,12 +105,13 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_kernel(const ScanArgs a
   const int f_w = ((rho_w >> 1) & 3) | ((wave & 1) << 2);
   const int c_w = sig ^ f_w;
   const size_t row_bytes = (size_t)D * 2;
+  int drot = 0;                            // K rotation of the DMA stream's group (wide_group_rotation)
   auto issue_piece = [&](uint32_t grp, int kg, int slot, int t) {
     uint32_t j = grp * NT + t;
     j = j < n_tiles ? j : n_tiles - 1;
     uint32_t row = (a.tile_first + j * a.tile_stride) * kTileRows + wave * 8 + rho_w;
     row = row < a.n_rows ? row : a.n_rows - 1;
-    const char* gp = (const char*)a.xb + (size_t)row * row_bytes + (size_t)kg * 128 + c_w * 16;
+    const char* gp = (const char*)a.xb + (size_t)row * row_bytes + (size_t)wide_rotated(kg, drot, KG) * 128 + c_w * 16;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                      (__attribute__((address_space(3))) void*)(smem + slot * STEP_BYTES + t * 4096 + wave * 1024), 16, 0, 2);
   };
@@ -115,8 +137,10 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_kernel(const ScanArgs a
   uint32_t grp = blockIdx.x;               // group being multiplied
   uint32_t dgrp = blockIdx.x;              // group / K step the DMA stream is at (two steps ahead)
   int dkg = 0, dslot = 0;
+  drot = wide_group_rotation(a, dgrp, NT, KG);       // K rotation of the DMA stream's group, of the compute group and of the next one
+  int rot = drot, rot_next = wide_group_rotation(a, blockIdx.x + gridDim.x, NT, KG);
   auto dma_advance = [&]() {
-    if (++dkg == KG) { dkg = 0; dgrp += gridDim.x; }
+    if (++dkg == KG) { dkg = 0; dgrp += gridDim.x; drot = wide_group_rotation(a, dgrp, NT, KG); }
     if (++dslot == NS) dslot = 0;
   };
   auto mfma4 = [&](auto r_tag, auto first_tag, frag x, frag q0, frag q1, frag q2, frag q3) {
@@ -141,7 +165,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_kernel(const ScanArgs a
     vm_wait_tied8<NT>(q[B][0][0], q[B][0][1], q[B][1][0], q[B][1][1], q[B][2][0], q[B][2][1], q[B][3][0], q[B][3][1]);
   };
   auto load_queries = [&](int buf, int kg) {
-    const char* sb = (const char*)a.xq + (size_t)kg * 128;
+    const char* sb = (const char*)a.xq + (size_t)kg * 128;   // kg: the (rotated) column, chosen by the caller
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) {
       query_load_frag(q[buf][qb][0], qoff[qb], sb, 0);
@@ -156,7 +180,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_kernel(const ScanArgs a
       for (int t = 0; t < NT; ++t) issue_piece(dgrp, dkg, dslot, t);
       dma_advance();
     }
-    load_queries(0, 0);
+    load_queries(0, wide_rotated(0, rot, KG));
 #pragma unroll
     for (int t = 0; t < NT; ++t) issue_piece(dgrp, dkg, dslot, t);
     dma_advance();
@@ -172,8 +196,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_kernel(const ScanArgs a
         // (this step's queries and, older in the queue, its slab pieces were waited for when the previous step closed)
         __builtin_amdgcn_s_barrier();
         {
-          int nkg = kgs + 1;
-          if (nkg == KG) nkg = 0;          // the next group starts over on the same queries
+          const int nkg = kgs + 1 == KG ? wide_rotated(0, rot_next, KG) : wide_rotated(kgs + 1, rot, KG);   // the next group starts over on the same queries
           load_queries(1 - P, nkg);
         }
         if (nb > 0) {
@@ -241,6 +264,8 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_kernel(const ScanArgs a
       });
     }
     grp += gridDim.x;
+    rot = rot_next;
+    rot_next = wide_group_rotation(a, grp + gridDim.x, NT, KG);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
   if (!DENSE) {
@@ -342,11 +367,13 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
   const size_t row_bytes = (size_t)D * 2;
   const char* dbase = (const char*)a.xb;   // uniform: first row of the DMA stream's group, + K offset
   uint32_t voff[NT];
+  int drot = 0;                            // K rotation of the DMA stream's group (wide_group_rotation)
 
   auto dma_new_group = [&](uint32_t grp) {
     if (grp >= n_groups) return;           // the stream runs ahead of the last group: it re-reads that one (valid memory, never used)
     const uint32_t row_base = (a.tile_first + grp * NT * a.tile_stride) * kTileRows;   // < n_rows: the group's first tile exists
     dbase = (const char*)a.xb + (size_t)row_base * row_bytes;
+    drot = wide_group_rotation(a, grp, NT, KG);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       uint32_t j = grp * NT + t;
@@ -357,7 +384,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
     }
   };
   auto issue_piece = [&](int kg, int slot, int t) {
-    const char* sb = dbase + (size_t)kg * 128;
+    const char* sb = dbase + (size_t)wide_rotated(kg, drot, KG) * 128;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voff[t]),
                                      (__attribute__((address_space(3))) void*)(smem + slot * STEP_BYTES + t * 4096 + wave * 1024), 16, 0, 2);
   };
@@ -410,6 +437,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
   uint32_t grp = blockIdx.x;               // group being multiplied
   uint32_t dgrp = blockIdx.x;              // group / K step the DMA stream is at (LEAD steps ahead)
   int dkg = 0, dslot = 0;
+  int rot = wide_group_rotation(a, grp, NT, KG), rot_next = wide_group_rotation(a, grp + gridDim.x, NT, KG);   // query side
   auto dma_advance = [&]() {
     if (++dkg == KG) { dkg = 0; dgrp += gridDim.x; dma_new_group(dgrp); }
     if (++dslot == NS) dslot = 0;
@@ -435,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
     // prologue in the steady-state issue order: DMA(0) | q(0) DMA(1) | q(1) DMA(2) | ... | q(PD-1) DMA(PD)
     dma_slab();
     static_for<PD>([&](auto i) {
-      if (nb > 0) load_queries(i, decltype(i)::value);
+      if (nb > 0) load_queries(i, wide_rotated(decltype(i)::value, rot, KG));
       dma_slab();
     });
     closing_wait();                        // DMA(0) and q(0) have landed
@@ -451,8 +479,8 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
     __builtin_amdgcn_s_barrier();          // slab s is complete in LDS (every wave waited for its pieces), slab s-1 is free
 #endif
     if (nb > 0) {
-      int nkg = kg + PD;
-      if (nkg >= KG) nkg -= KG;            // the next group starts over on the same queries
+      // column of the queries PD steps ahead; past the end of this group the next one starts over on the same queries, in ITS order
+      const int nkg = kg + PD >= KG ? wide_rotated(kg + PD - KG, rot_next, KG) : wide_rotated(kg + PD, rot, KG);
 #if RR_WIDE_SPREAD
       // The CU's four waves run this code in lockstep (one barrier per step) and share ONE address unit: issued together, their
       // vector-memory instructions queue behind each other there and each holds its in-order wave ~60 cycles, with the matrix
@@ -566,6 +594,8 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
       });
     }
     grp += gridDim.x;
+    rot = rot_next;
+    rot_next = wide_group_rotation(a, grp + gridDim.x, NT, KG);
   }
   // No LDS-DMA may outlive the workgroup - and no prefetched query load may outlive the LOOP: the sets of the steps that will
   // never run are still landing in the q registers, which hipcc regards as free from here on.  It computed the addresses of the
@@ -659,10 +689,12 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
   const size_t row_bytes = (size_t)D * 2;
   const char* dbase = (const char*)a.xb;
   uint32_t voff[NPW];
+  int drot = 0;
   auto dma_new_group = [&](uint32_t grp) {
     if (grp >= n_groups) return;
     const uint32_t row_base = (a.tile_first + grp * NT * a.tile_stride) * kTileRows;
     dbase = (const char*)a.xb + (size_t)row_base * row_bytes;
+    drot = wide_group_rotation(a, grp, NT, KG);
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
       uint32_t j = grp * NT + tbase + i;
@@ -673,7 +705,7 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
     }
   };
   auto issue_piece = [&](int kg, int slot, int i) {
-    const char* sb = dbase + (size_t)kg * 128;
+    const char* sb = dbase + (size_t)wide_rotated(kg, drot, KG) * 128;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voff[i]),
                                      (__attribute__((address_space(3))) void*)(smem + slot * STEP_BYTES + (tbase + i) * 4096 + oct * 1024), 16, 0, 2);
   };
@@ -723,6 +755,7 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
 
   uint32_t grp = blockIdx.x, dgrp = blockIdx.x;
   int dkg = 0, dslot = 0;
+  int rot = wide_group_rotation(a, grp, NT, KG), rot_next = wide_group_rotation(a, grp + gridDim.x, NT, KG);
   auto dma_advance = [&]() {
     if (++dkg == KG) { dkg = 0; dgrp += gridDim.x; dma_new_group(dgrp); }
     if (++dslot == NS) dslot = 0;
@@ -740,7 +773,7 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
     dma_new_group(dgrp);
     dma_slab();
     static_for<PD>([&](auto i) {
-      if (nb > 0) load_queries(i, decltype(i)::value);
+      if (nb > 0) load_queries(i, wide_rotated(decltype(i)::value, rot, KG));
       dma_slab();
     });
     closing_wait();
@@ -754,8 +787,7 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
     constexpr int PN = (P + PD) % QB;
     __builtin_amdgcn_s_barrier();
     if (nb > 0) {
-      int nkg = kg + PD;
-      if (nkg >= KG) nkg -= KG;
+      const int nkg = kg + PD >= KG ? wide_rotated(kg + PD - KG, rot_next, KG) : wide_rotated(kg + PD, rot, KG);
 #if RR_WIDE8_SPREAD
       const char* qsb = RR_WIDE_QBASE(a) + (size_t)nkg * RR_WIDE_QSTEP;   // query loads go into the first half of the MFMA stream, 4 fragments apart
 #else
@@ -842,6 +874,8 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
       });
     }
     grp += gridDim.x;
+    rot = rot_next;
+    rot_next = wide_group_rotation(a, grp + gridDim.x, NT, KG);
   }
   // (the wait is tied to every q register: see the end of flat_scan_wide_pd_kernel)
   static_for<QB * NQB>([&](auto i) {

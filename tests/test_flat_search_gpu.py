@@ -321,3 +321,25 @@ def test_more_than_one_query_block_at_half_resident_widths(gpu, d, nq):
     D, I = _index(gpu, xb, d).search(xq, 10)
     Dr, Ir = O.flat_search_ip(xb, xq, 10)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
+@pytest.mark.parametrize("d", [2048, 4096, 1792])
+def test_wide_row_scores_do_not_depend_on_batch_size_or_k(gpu, d):
+    """Rows wider than 1536 walk their K loop in a rotated order that is a function of the global 256-row group alone
+    (flat_scan_wide.hip): the same (query, row) must score bit-identically whatever kernel instance (1 query, 17, 256), chunk
+    schedule (k = 10 vs 100 moves the chunk boundaries) or launch (sample vs chunk) computes it - on gaussian data, where a
+    different summation order WOULD show in the last bits."""
+    rng = np.random.default_rng(d)
+    n = 70_001
+    xb = half_round(rng.standard_normal((n, d)).astype(np.float32) / np.sqrt(d))
+    xq = half_round(rng.standard_normal((256, d)).astype(np.float32))
+    idx = _index(gpu, xb, d)
+    D100, I100 = idx.search(xq, 100)
+    D10, I10 = idx.search(xq, 10)
+    assert np.array_equal(I10, I100[:, :10]) and np.array_equal(D10, D100[:, :10])
+    for sub in (1, 17, 130):
+        Ds, Is = idx.search(xq[:sub], 100)
+        assert np.array_equal(Is, I100[:sub]) and np.array_equal(Ds, D100[:sub])
+    from oracle import oracle as O
+    Dref, Iref = O.flat_search_ip(xb, xq[:32], 100)
+    assert_topk_close(D100[:32], I100[:32], Dref, Iref)
