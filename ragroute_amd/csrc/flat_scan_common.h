@@ -259,7 +259,8 @@ struct LaneState4 {
 __device__ __forceinline__ float max4v(const f32x4& v) { return max4(v[0], v[1], v[2], v[3]); }
 
 // INLINE_COMPACT: no function call in the slow path (for kernels that keep asynchronously loaded registers live across it)
-template <bool DENSE, int NQB, int QPW = 64, bool INLINE_COMPACT = false>
+// QPW: queries per wave (the wave's queries are wave * QPW + qb * 16 + col); WAVES: waves per workgroup (compaction scratch slots)
+template <bool DENSE, int NQB, int QPW = 64, bool INLINE_COMPACT = false, int WAVES = 256 / QPW>
 __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& st, f32x4 (&acc)[2][4], uint32_t j, int lane, int wave) {
   const int col = lane & 15, g = lane >> 4;
   const uint32_t tile = a.tile_first + j * a.tile_stride;
@@ -323,7 +324,7 @@ __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& s
 #pragma unroll
   for (int qb = 0; qb < NQB; ++qb) full = full || st.cnt[qb] > lim;
   if (__builtin_amdgcn_ballot_w64(full)) {
-    uint64_t* scratch = a.scratch + (size_t)(blockIdx.x * (256 / QPW) + wave) * a.cap;
+    uint64_t* scratch = a.scratch + (size_t)(blockIdx.x * WAVES + wave) * a.cap;
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
       uint64_t mask = __builtin_amdgcn_ballot_w64(st.cnt[qb] > lim);

@@ -340,6 +340,8 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
   constexpr int NF = 4 * NT;               // A fragments per K step: (tile, s2, rb)
   constexpr int NB = NF < 8 ? NF : 8;
   constexpr int NQL = 2 * NQB;             // query loads per step and wave
+  constexpr int QPW = 16 * NQB;            // queries per wave: the batch is dealt to the four waves in blocks of 16, NQB each (1 for up
+                                           // to 64 queries, 2 up to 128, 4 up to 256) so that every SIMD carries a quarter of the MFMAs
   constexpr int WAIT_Q = NT * PD + NQL * (PD - 1);  // ops younger than q(s+1) at the end of step s (waves holding queries)
   constexpr int WAIT_0 = NT * PD;                   // ... for a wave without queries: DMA(s+2) .. DMA(s+LEAD)
   static_assert(WAIT_Q <= 63, "vmcnt range");
@@ -390,14 +392,14 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
   };
 
   // query blocks of this wave that hold real queries (wave-uniform); a kernel instance serves NQB blocks per wave
-  const int nb = __builtin_amdgcn_readfirstlane((int)a.nq <= wave * 64 ? 0 : ((int)a.nq - wave * 64 + 15) / 16);
+  const int nb = __builtin_amdgcn_readfirstlane((int)a.nq <= wave * QPW ? 0 : ((int)a.nq - wave * QPW + 15) / 16);
   uint32_t qoff[NQB];
 #pragma unroll
   for (int qb = 0; qb < NQB; ++qb) {
-#if RR_WIDE_QFRAG   // [16-query block wave*4+qb][k slice][lane][8]: slots past nq repeat the last query (prep_kernel)
-    qoff[qb] = (uint32_t)(wave * 4 + qb) * (uint32_t)(D * 32) + 16 * lane;
+#if RR_WIDE_QFRAG   // [16-query block wave*NQB+qb][k slice][lane][8]: slots past nq repeat the last query (prep_kernel)
+    qoff[qb] = (uint32_t)(wave * NQB + qb) * (uint32_t)(D * 32) + 16 * lane;
 #else
-    const uint32_t qi = wave * 64 + qb * 16 + col;
+    const uint32_t qi = wave * QPW + qb * 16 + col;
     qoff[qb] = (qi < a.nq ? qi : a.nq - 1) * (uint32_t)(D * 2) + 16 * g;
 #endif
   }
@@ -405,8 +407,8 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
   const uint32_t nbuf = gridDim.x * 4;
 #pragma unroll
   for (int qb = 0; qb < 4; ++qb) {
-    const uint32_t qi = wave * 64 + qb * 16 + col;
-    st.thr[qb] = DENSE ? 0.f : a.thr[qi];
+    const uint32_t qi = wave * QPW + (qb < NQB ? qb : 0) * 16 + col;   // (slots past NQB are never used)
+    st.thr[qb] = (DENSE || qb >= NQB) ? 0.f : a.thr[qi];
 #if RR_WIDE_ABL
     st.thr[qb] = __builtin_inff();   // ablated steps produce garbage scores: nothing may enter the insertion path
 #endif
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
               e[1][qb] -= h1;
             }
           }
-          tile_epilogue16<DENSE, NQB, 64, true>(a, st, e, j, lane, wave);
+          tile_epilogue16<DENSE, NQB, QPW, true, 4>(a, st, e, j, lane, wave);
         }
       });
     }
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
   });
   if (!DENSE) {
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) a.cand_cnt[(wave * 64 + qb * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
+    for (int qb = 0; qb < NQB; ++qb) a.cand_cnt[(wave * QPW + qb * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
   }
 }
 
@@ -658,7 +660,7 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
   typedef typename Mfma<T>::frag frag;
   constexpr int NT = 8;                    // 32-row tiles per group
   constexpr int STEP_BYTES = NT * 4096;    // one K step of one group in LDS
-  constexpr int QPW = 32;                  // queries per wave
+  constexpr int QPW = 16 * NQB;            // queries per wave: blocks of 16 dealt to the waves, NQB each (1 up to 64 queries, 2 up to 256)
   constexpr int QB = PD + 1, LEAD = PD + 1, NS = LEAD + 1;
   constexpr int NF = 4 * NT;               // A fragments per K step: (tile, s2, rb)
   constexpr int NB = RR_WIDE8_RING;
@@ -715,7 +717,7 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
 #pragma unroll
   for (int qb = 0; qb < NQB; ++qb) {
 #if RR_WIDE_QFRAG
-    qoff[qb] = (uint32_t)(wave * 2 + qb) * (uint32_t)(D * 32) + 16 * lane;
+    qoff[qb] = (uint32_t)(wave * NQB + qb) * (uint32_t)(D * 32) + 16 * lane;
 #else
     const uint32_t qi = wave * QPW + qb * 16 + col;
     qoff[qb] = (qi < a.nq ? qi : a.nq - 1) * (uint32_t)(D * 2) + 16 * g;
@@ -725,8 +727,8 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
   const uint32_t nbuf = gridDim.x * 4;
 #pragma unroll
   for (int qb = 0; qb < 4; ++qb) {
-    const uint32_t qi = wave * QPW + (qb & 1) * 16 + col;
-    st.thr[qb] = qb < 2 ? a.thr[qi] : 0.f;
+    const uint32_t qi = wave * QPW + (qb < NQB ? qb : 0) * 16 + col;
+    st.thr[qb] = qb < NQB ? a.thr[qi] : 0.f;
 #if RR_WIDE_ABL || RR_WIDE8_ABL
     st.thr[qb] = __builtin_inff();
 #endif
@@ -869,7 +871,7 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
               e[1][qb] -= h1;
             }
           }
-          tile_epilogue16<false, NQB, QPW, true>(a, st, e, j, lane, wave);
+          tile_epilogue16<false, NQB, QPW, true, 8>(a, st, e, j, lane, wave);
         }
       });
     }
@@ -883,7 +885,7 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
     vm_drain_tied(q[b][qb][0], q[b][qb][1]);
   });
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) a.cand_cnt[(wave * QPW + qb * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
+  for (int qb = 0; qb < NQB; ++qb) a.cand_cnt[(wave * QPW + qb * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
 }
 
 static int wide_pd() {  // RR_WIDE_PD: 0 = the round-1 kernel (one slab in flight), 2 / 3 = query prefetch distance of the deeper pipeline
@@ -912,7 +914,11 @@ static hipError_t launch_scan_wide_t(const ScanArgs& a, int D, bool dense, int g
   const int pd = wide_pd();
   const size_t lds = (size_t)(pd == 0 ? 3 : pd + 2) * (dense ? 1 : 8) * 4096;
   const bool l2 = a.half_sqnorm != nullptr;
-  const bool few = a.nq <= 16;           // one query block per wave at most: a quarter of the MFMA work
+  // query blocks (16 queries) per wave: the batch is dealt evenly to the waves, so 17 ... 128 queries no longer sit on one or two SIMDs
+  const int nqb4 = a.nq <= 64 ? 1 : a.nq <= 128 ? 2 : 4;   // four-wave kernel
+  const bool one8 = a.nq <= 64;                            // eight-wave kernel: 1 block per wave up to 64 queries (measured at d = 2048,
+                                                           // 128 queries: 2 blocks on four waves 0.76, 1 block on eight 0.73 - every LDS
+                                                           // fragment read then feeds one MFMA instead of two)
   hipError_t e;
 #define RR_LAUNCH_KERNEL(...)                                                                                        \
   {                                                                                                                  \
@@ -940,20 +946,27 @@ static hipError_t launch_scan_wide_t(const ScanArgs& a, int D, bool dense, int g
     hipLaunchKernelGGL((__VA_ARGS__), dim3(grid), dim3(512), lds, st, a, D);                                        \
     return hipGetLastError();                                                                                        \
   }
-    if (l2) { if (few) RR_LAUNCH_8(flat_scan_wide8_kernel<T, true, 1, 2>) else RR_LAUNCH_8(flat_scan_wide8_kernel<T, true, 2, 2>) }
-    if (few) RR_LAUNCH_8(flat_scan_wide8_kernel<T, false, 1, 2>) else RR_LAUNCH_8(flat_scan_wide8_kernel<T, false, 2, 2>)
+    if (l2) { if (one8) RR_LAUNCH_8(flat_scan_wide8_kernel<T, true, 1, 2>) else RR_LAUNCH_8(flat_scan_wide8_kernel<T, true, 2, 2>) }
+    if (one8) RR_LAUNCH_8(flat_scan_wide8_kernel<T, false, 1, 2>) else RR_LAUNCH_8(flat_scan_wide8_kernel<T, false, 2, 2>)
 #undef RR_LAUNCH_8
   }
   if (pd == 0) {
     if (l2) { if (dense) RR_LAUNCH_KERNEL(flat_scan_wide_kernel<T, true, true>) else RR_LAUNCH_KERNEL(flat_scan_wide_kernel<T, false, true>) }
     if (dense) RR_LAUNCH_KERNEL(flat_scan_wide_kernel<T, true, false>) else RR_LAUNCH_KERNEL(flat_scan_wide_kernel<T, false, false>)
   }
-  if (l2) {
-    if (dense) { if (few) RR_LAUNCH_PD(true, true, 1) else RR_LAUNCH_PD(true, true, 4) }
-    if (few) RR_LAUNCH_PD(false, true, 1) else RR_LAUNCH_PD(false, true, 4)
+#define RR_LAUNCH_PD_N(DENSE_, L2_)                      \
+  {                                                      \
+    if (nqb4 == 1) RR_LAUNCH_PD(DENSE_, L2_, 1)          \
+    if (nqb4 == 2) RR_LAUNCH_PD(DENSE_, L2_, 2)          \
+    RR_LAUNCH_PD(DENSE_, L2_, 4)                         \
   }
-  if (dense) { if (few) RR_LAUNCH_PD(true, false, 1) else RR_LAUNCH_PD(true, false, 4) }
-  if (few) RR_LAUNCH_PD(false, false, 1) else RR_LAUNCH_PD(false, false, 4)
+  if (l2) {
+    if (dense) RR_LAUNCH_PD_N(true, true)
+    RR_LAUNCH_PD_N(false, true)
+  }
+  if (dense) RR_LAUNCH_PD_N(true, false)
+  RR_LAUNCH_PD_N(false, false)
+#undef RR_LAUNCH_PD_N
 #undef RR_LAUNCH_PD
 #undef RR_LAUNCH_KERNEL
 }
