@@ -88,9 +88,11 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
                                        (__attribute__((address_space(3))) void*)(l + kg * 4096), 16, 0, 0);
   };
 
-  // real query blocks of this wave (wave-uniform)
-  const int nb = __builtin_amdgcn_readfirstlane(
-      (int)a.nq <= wave * 64 ? 0 : ((int)a.nq - wave * 64 >= 64 ? 4 : ((int)a.nq - wave * 64 + 15) / 16));
+  // The batch is dealt to the four waves in blocks of 16 queries, round robin: slot qb of wave w holds block 4 qb + w, so 128
+  // queries are 2 blocks on every SIMD instead of 4 on two of them (the step is bound by the busiest wave's MFMAs).
+  // Real query blocks of this wave (wave-uniform): slots 0 .. nb-1
+  const int nblk = ((int)a.nq + 15) >> 4;
+  const int nb = __builtin_amdgcn_readfirstlane(nblk > wave ? (nblk - wave + 3) >> 2 : 0);
 
   // L2: |x|^2/2 of the 32 rows of tile ordinal jj -> LDS floats [NS*TILE_BYTES + slot*256 ...] (lanes 32..63 duplicate)
   auto issue_norms = [&](uint32_t jj, int slot_) {
@@ -117,14 +119,14 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   }
 
   // (the first two tiles are already in flight: their HBM latency overlaps the query loads below)
-  // ---- resident queries: B fragment (qb, s2): query wave*64 + qb*16 + col, k = 32 s2 + 8 g .. +7 -------------
+  // ---- resident queries: B fragment (qb, s2): query (4 qb + wave)*16 + col, k = 32 s2 + 8 g .. +7 -------------
   // (read from the fragment-order copy the prep kernel made, a.xqs: every load is one contiguous KiB per wave)
   frag q[4][KS2];
   {
     const T* xqs = (const T*)a.xqs;
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) {
-      const T* p = xqs + ((size_t)(wave * 4 + qb) * KS2 * 64 + lane) * 8;
+      const T* p = xqs + ((size_t)(qb * 4 + wave) * KS2 * 64 + lane) * 8;
 #pragma unroll
       for (int s2 = 0; s2 < KS2; ++s2) {
         if (qb * KS2 + s2 < NAQ) agpr_load_frag(q[qb][s2], p + 512 * s2);
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   const uint32_t nbuf = gridDim.x * 4;
 #pragma unroll
   for (int qb = 0; qb < 4; ++qb) {
-    const uint32_t qi = wave * 64 + qb * 16 + col;
+    const uint32_t qi = (qb * 4 + wave) * 16 + col;
     st.thr[qb] = DENSE ? 0.f : a.thr[qi];
     st.cnt[qb] = 0;
     st.off[qb] = (qi * nbuf + blockIdx.x * 4 + g) * (uint32_t)a.cap;
@@ -216,6 +218,10 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
         asm volatile("s_nop 15\n\ts_nop 7"
                      : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),
                        "+v"(acc[1][2]), "+v"(acc[1][3]));
+      else if (NQB == 3)
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]));
+      else if (NQB == 2)
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
       else
         asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][0]));
       if (std::is_same<T, I8Pair>::value) {
@@ -235,10 +241,14 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
           acc[1][qb] -= h1;
         }
       }
-      tile_epilogue16<DENSE, NQB>(a, st, acc, j, lane, wave);
+      tile_epilogue16<DENSE, NQB, 64, false, 4, true>(a, st, acc, j, lane, wave);
     };
-    if (nb >= 2) {
+    if (nb >= 4) {
       compute(std::integral_constant<int, 4>{});
+    } else if (nb == 3) {
+      compute(std::integral_constant<int, 3>{});
+    } else if (nb == 2) {
+      compute(std::integral_constant<int, 2>{});
     } else if (nb == 1) {
       compute(std::integral_constant<int, 1>{});
     } else {
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
   if (!DENSE) {
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) a.cand_cnt[(wave * 64 + qb * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
+    for (int qb = 0; qb < 4; ++qb) a.cand_cnt[((qb * 4 + wave) * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
   }
   if (a.timeline && threadIdx.x == 0) {
     a.timeline[gridDim.x + blockIdx.x] = __builtin_amdgcn_s_memrealtime();

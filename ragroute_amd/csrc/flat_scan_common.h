@@ -259,15 +259,16 @@ struct LaneState4 {
 __device__ __forceinline__ float max4v(const f32x4& v) { return max4(v[0], v[1], v[2], v[3]); }
 
 // INLINE_COMPACT: no function call in the slow path (for kernels that keep asynchronously loaded registers live across it)
-// QPW: queries per wave (the wave's queries are wave * QPW + qb * 16 + col); WAVES: waves per workgroup (compaction scratch slots)
-template <bool DENSE, int NQB, int QPW = 64, bool INLINE_COMPACT = false, int WAVES = 256 / QPW>
+// QPW: queries per wave (the wave's queries are wave * QPW + qb * 16 + col); WAVES: waves per workgroup (compaction scratch slots);
+// DEAL: the query blocks are dealt round robin instead (slot qb of wave w = block 4 qb + w: flat_scan16_kernel)
+template <bool DENSE, int NQB, int QPW = 64, bool INLINE_COMPACT = false, int WAVES = 256 / QPW, bool DEAL = false>
 __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& st, f32x4 (&acc)[2][4], uint32_t j, int lane, int wave) {
   const int col = lane & 15, g = lane >> 4;
   const uint32_t tile = a.tile_first + j * a.tile_stride;
   if (DENSE) {
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
-      float* d = a.dense + (size_t)(wave * QPW + qb * 16 + col) * a.dense_ld + j * kTileRows + 4 * g;
+      float* d = a.dense + (size_t)(DEAL ? (qb * 4 + wave) * 16 + col : wave * QPW + qb * 16 + col) * a.dense_ld + j * kTileRows + 4 * g;
       *(f32x4*)d = acc[0][qb];
       *(f32x4*)(d + 16) = acc[1][qb];
     }
