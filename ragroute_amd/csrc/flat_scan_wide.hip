@@ -61,12 +61,14 @@ __device__ __forceinline__ void vm_wait_tied8(F& r0, F& r1, F& r2, F& r3, F& r4,
 #define RR_WIDE_KROT 5   // 0: every group starts at column 0 (A/B)
 #endif
 __device__ __forceinline__ int wide_group_rotation(const ScanArgs& a, uint32_t grp, int tiles_per_group, int KG) {
-  // only where the row pitch is a multiple of 2 KiB (d = 2048, 3072, 4096): other pitches spread over the channels by themselves
-  // (d = 1792: one query 0.845 without, 0.80 with), at d = 8192 the rotated query block (4 MB) no longer fits an XCD's L2 (256
-  // queries -2.9 %), and d <= 1536 is also served by the half-resident kernel, which has no rotation
-  if (!RR_WIDE_KROT || KG <= 24 || KG > 64 || (KG & 15)) return 0;
+  // only where the row pitch is a multiple of 4 KiB (d = 2048, 4096, 6144, 8192): other pitches spread over the channels by
+  // themselves (d = 1792: one query 0.845 without, 0.80 with; d = 3072 and 5120: no gain), and d <= 1536 is also served by the
+  // half-resident kernel, which has no rotation.  Rows wider than 4096 rotate within a window of 64 columns: with the whole K range
+  // in flight the 4 MB query block of d = 8192 no longer fits an XCD's L2 (256 queries -2.9 %); windowed: one query 0.79 -> 0.83
+  // (d = 8192) and 0.77 -> 0.82 (d = 6144), 256 queries unchanged.
+  if (!RR_WIDE_KROT || KG <= 24 || (KG & 31)) return 0;
   const uint32_t m = (a.tile_first + grp * (uint32_t)tiles_per_group * a.tile_stride) >> 3;
-  return (int)((m * (uint32_t)RR_WIDE_KROT) % (uint32_t)KG);
+  return (int)((m * (uint32_t)RR_WIDE_KROT) % (uint32_t)(KG > 64 ? 64 : KG));
 }
 __device__ __forceinline__ int wide_rotated(int kg, int rot, int KG) { return kg + rot >= KG ? kg + rot - KG : kg + rot; }
 

@@ -323,7 +323,7 @@ def test_more_than_one_query_block_at_half_resident_widths(gpu, d, nq):
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
 
 
-@pytest.mark.parametrize("d", [2048, 4096, 1792])
+@pytest.mark.parametrize("d", [2048, 4096, 1792, 6144])
 def test_wide_row_scores_do_not_depend_on_batch_size_or_k(gpu, d):
     """Rows wider than 1536 walk their K loop in a rotated order that is a function of the global 256-row group alone
     (flat_scan_wide.hip): the same (query, row) must score bit-identically whatever kernel instance (1 query, 17, 256), chunk
