@@ -342,8 +342,11 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
   constexpr int NF = 4 * NT;               // A fragments per K step: (tile, s2, rb)
   constexpr int NB = NF < 8 ? NF : 8;
   constexpr int NQL = 2 * NQB;             // query loads per step and wave
-  // The batch is dealt to the four waves in blocks of 16 queries, round robin: slot qb of wave w holds block 4 qb + w, and the kernel
-  // is instantiated for NQB = 1 ... 4 slots (up to 64 / 128 / 192 / 256 queries), so every SIMD carries a quarter of the MFMAs.
+  // The batch is dealt to the four waves in blocks of 16 queries, NQB consecutive blocks per wave, and the kernel is instantiated
+  // for NQB = 1 ... 4 (up to 64 / 128 / 192 / 256 queries), so that no SIMD carries more than a quarter of the MFMAs.  (Consecutive,
+  // not round robin: a wave computes all NQB slots of its instance or none, so 9 blocks are 3 + 3 + 3 + 0 = 9 computed slots
+  // against 12 round robin - same busiest wave, fewer MFMAs under the power cap: 65 queries at d = 4096 0.81 against 0.74.)
+  constexpr int QPW = 16 * NQB;
   constexpr int WAIT_Q = NT * PD + NQL * (PD - 1);  // ops younger than q(s+1) at the end of step s (waves holding queries)
   constexpr int WAIT_0 = NT * PD;                   // ... for a wave without queries: DMA(s+2) .. DMA(s+LEAD)
   static_assert(WAIT_Q <= 63, "vmcnt range");
@@ -394,15 +397,14 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
   };
 
   // query blocks of this wave that hold real queries (wave-uniform); a kernel instance serves NQB blocks per wave
-  const int nblk = ((int)a.nq + 15) >> 4;
-  const int nb = __builtin_amdgcn_readfirstlane(nblk > wave ? (nblk - wave + 3) >> 2 : 0);
+  const int nb = __builtin_amdgcn_readfirstlane((int)a.nq <= wave * QPW ? 0 : ((int)a.nq - wave * QPW + 15) / 16);
   uint32_t qoff[NQB];
 #pragma unroll
   for (int qb = 0; qb < NQB; ++qb) {
-#if RR_WIDE_QFRAG   // [16-query block 4*qb+wave][k slice][lane][8]: slots past nq repeat the last query (prep_kernel)
-    qoff[qb] = (uint32_t)(qb * 4 + wave) * (uint32_t)(D * 32) + 16 * lane;
+#if RR_WIDE_QFRAG   // [16-query block wave*NQB+qb][k slice][lane][8]: slots past nq repeat the last query (prep_kernel)
+    qoff[qb] = (uint32_t)(wave * NQB + qb) * (uint32_t)(D * 32) + 16 * lane;
 #else
-    const uint32_t qi = (qb * 4 + wave) * 16 + col;
+    const uint32_t qi = wave * QPW + qb * 16 + col;
     qoff[qb] = (qi < a.nq ? qi : a.nq - 1) * (uint32_t)(D * 2) + 16 * g;
 #endif
   }
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
   const uint32_t nbuf = gridDim.x * 4;
 #pragma unroll
   for (int qb = 0; qb < 4; ++qb) {
-    const uint32_t qi = ((qb < NQB ? qb : 0) * 4 + wave) * 16 + col;   // (slots past NQB are never used)
+    const uint32_t qi = wave * QPW + (qb < NQB ? qb : 0) * 16 + col;   // (slots past NQB are never used)
     st.thr[qb] = (DENSE || qb >= NQB) ? 0.f : a.thr[qi];
 #if RR_WIDE_ABL
     st.thr[qb] = __builtin_inff();   // ablated steps produce garbage scores: nothing may enter the insertion path
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
               e[1][qb] -= h1;
             }
           }
-          tile_epilogue16<DENSE, NQB, 64, true, 4, true>(a, st, e, j, lane, wave);
+          tile_epilogue16<DENSE, NQB, QPW, true, 4>(a, st, e, j, lane, wave);
         }
       });
     }
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
   });
   if (!DENSE) {
 #pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) a.cand_cnt[((qb * 4 + wave) * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
+    for (int qb = 0; qb < NQB; ++qb) a.cand_cnt[(wave * QPW + qb * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
   }
 }
 
@@ -918,7 +920,7 @@ static hipError_t launch_scan_wide_t(const ScanArgs& a, int D, bool dense, int g
   const size_t lds = (size_t)(pd == 0 ? 3 : pd + 2) * (dense ? 1 : 8) * 4096;
   const bool l2 = a.half_sqnorm != nullptr;
   // query blocks (16 queries) per wave: the batch is dealt evenly to the waves, so 17 ... 128 queries no longer sit on one or two SIMDs
-  const int nqb4 = a.nq <= 64 ? 1 : a.nq <= 128 ? 2 : a.nq <= 192 ? 3 : 4;   // four-wave kernel (blocks dealt round robin)
+  const int nqb4 = a.nq <= 64 ? 1 : a.nq <= 128 ? 2 : a.nq <= 192 ? 3 : 4;   // four-wave kernel (consecutive blocks per wave)
   const bool one8 = a.nq <= 64;                            // eight-wave kernel: 1 block per wave up to 64 queries (measured at d = 2048,
                                                            // 128 queries: 2 blocks on four waves 0.76, 1 block on eight 0.73 - every LDS
                                                            // fragment read then feeds one MFMA instead of two)
