@@ -912,6 +912,16 @@ static int wide_waves(int D) {
   }();
   return forced ? forced : (D <= 2048 ? 8 : 4);
 }
+// 129 ... 192 queries at d <= 2048: the 8-wave kernel deals 2 blocks per wave, so two SIMDs carry two busy waves and two carry one;
+// the 4-wave kernel's 3-block instance is level.  Measured (2M x 2048 / 4M x 1024, scan fraction): 129 queries 0.61 -> 0.66,
+// 160 queries 0.605 (8 waves) against 0.59, 192 queries 0.575 -> 0.60, 224 and 256 queries 8 waves (0.54 / 0.51 against 0.505 / 0.50).
+static int wide_waves_for(int D, int nq) {
+  const int w = wide_waves(D);
+  static const bool forced = getenv("RR_WIDE_WAVES") != nullptr;
+  if (forced || w != 8) return w;
+  const int nblk = (nq + 15) / 16;
+  return (nblk == 9 || nblk == 11 || nblk == 12) ? 4 : 8;
+}
 
 template <typename T>
 static hipError_t launch_scan_wide_t(const ScanArgs& a, int D, bool dense, int grid, hipStream_t st) {
@@ -942,7 +952,7 @@ static hipError_t launch_scan_wide_t(const ScanArgs& a, int D, bool dense, int g
     RR_PD3_CASE(DENSE_, L2_, NQB_)                                                        \
     RR_LAUNCH_KERNEL(flat_scan_wide_pd_kernel<T, DENSE_, L2_, NQB_, 2>)                   \
   }
-  if (!dense && pd != 0 && wide_waves(D) == 8) {
+  if (!dense && pd != 0 && wide_waves_for(D, (int)a.nq) == 8) {
     hipError_t e8;
 #define RR_LAUNCH_8(...)                                                                                             \
   {                                                                                                                  \
