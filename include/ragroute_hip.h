@@ -30,6 +30,10 @@ enum { RR_MAX_K = 1024, RR_QUERY_BLOCK = 256 };
 
 /* Library version (major*10000 + minor*100 + patch). */
 int rr_version(void);
+/* The compiler flags this library was built with (ragroute_amd/_build.py).  A product build carries no -D switch: the
+ * development kernels (RR_DEV_VARIANTS) and the timing-only ablations that exist inside such builds are then not compiled
+ * in, and a test can tell the library under test from an A/B build. */
+const char* rr_build_flags(void);
 /* Message of the last failure on the calling thread ("" if none). */
 const char* rr_last_error(void);
 /* Number of compute units of the current device (the persistent scan grid), or <0 on error. */
@@ -128,6 +132,15 @@ int rr_profile_end(double* scan_ms_total, int* n_launches, double* rows_scanned)
  *   d_Din f32 [nq][m], d_Iin i64 [nq][m]  ->  d_Dout f32 [nq][k], d_Iout i64 [nq][k]. m <= 8192. */
 int rr_merge_topk(const float* d_Din, const int64_t* d_Iin, int nq, int m, int k, int descending,
                   float* d_Dout, int64_t* d_Iout, void* stream);
+
+/* The same merge reading the candidate exchange buffer in place, as the all-gather left it (no repacking copies):
+ * n_ranks blocks, rank_stride_bytes apart, each `D f32 [slots][nq][k_in]` at offset 0 and `I i64 [slots][nq][k_in]` at
+ * ids_offset_bytes (one slot per data source the rank holds; unused slots are padding (-inf, -1)).  Candidate order per
+ * query = rank-major, then slot, then the source's own best-first order: the concatenation the reference's front-end
+ * builds from the per-source replies (ragroute/http_server.py:280-286) before rerank.py:3-9.
+ * n_ranks * slots * k_in <= 8192; both byte counts multiples of 8. */
+int rr_merge_topk_gathered(const void* d_gathered, int n_ranks, size_t rank_stride_bytes, size_t ids_offset_bytes, int slots,
+                           int nq, int k_in, int k, int descending, float* d_Dout, int64_t* d_Iout, void* stream);
 
 /* Router MLP (CorpusRoutingNN) with the feature build and StandardScaler folded into fc1.
  * Replaces, for a batch of queries, reference ragroute/router.py:241-283

@@ -21,8 +21,11 @@ LLVM_BIN = os.environ.get("RR_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 FIXED_AGPR_KERNELS = ("flat_scan_wide",)   # flat_scan_wide_kernel, _pd_kernel, wide8_kernel
 
 
+PRODUCT_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"]   # what rr_build_flags() of a product library reports
+
+
 def _flags():
-    flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"]
+    flags = list(PRODUCT_FLAGS)
     if os.environ.get("RR_DEV_VARIANTS") or os.environ.get("RR_ABLATION_VARIANTS"):
         flags.append("-DRR_DEV_VARIANTS")      # the measured alternatives of flat_scan_dev.hip (RR_SCAN_VARIANT / RR_GENERIC_TALL)
     if os.environ.get("RR_ABLATION_VARIANTS"):
@@ -152,6 +155,12 @@ def build(force=False, verbose=False):
     todo = [(src, obj) for src, obj, stale in jobs if stale]
     if not todo and os.path.exists(lib_path) and all(os.path.getmtime(lib_path) >= os.path.getmtime(o) for _, o, _ in jobs):
         return lib_path
+
+    # rr_build_flags(): capi.hip includes the flag string as a C literal
+    inc = os.path.join(OBJ_DIR, "rr_build_flags.inc")
+    literal = '"' + " ".join(flags).replace("\\", "\\\\").replace('"', '\\"') + '"\n'
+    if not os.path.exists(inc) or open(inc).read() != literal:
+        open(inc, "w").write(literal)
 
     def compile_one(job):
         src, obj = job

@@ -122,9 +122,19 @@ Workspace carve(char* base, int k, int grid) {
 
 }  // namespace
 
+// The compile flags of this library, written by ragroute_amd/_build.py next to the objects before it compiles this unit.
+#if __has_include("build/rr_build_flags.inc")
+const char kBuildFlags[] =
+#include "build/rr_build_flags.inc"
+    ;
+#else
+const char kBuildFlags[] = "unknown (not built by ragroute_amd/_build.py)";
+#endif
+
 extern "C" {
 
-int rr_version(void) { return 300; }  // 0.3.0: prep kernel (fragment-order queries), fused finalize, deeper wide-row pipeline, size-aware chunk schedule
+int rr_version(void) { return 400; }  // 0.4.0: segmented search, in-place merge of the exchange buffer, rr_build_flags
+const char* rr_build_flags(void) { return kBuildFlags; }
 const char* rr_last_error(void) { return g_err; }
 int rr_device_cus(void) {
   int v = device_cus();
@@ -386,8 +396,27 @@ int rr_merge_topk(const float* Din, const int64_t* Iin, int nq, int m, int k, in
   if (m > rr::kSelectCap) return fail(RR_ERR_UNSUPPORTED, "rr_merge_topk: m > 8192 candidates per query%s");
   if (nq == 0) return RR_OK;
   if ((m > 0 && (!Din || !Iin)) || !Dout || !Iout) return fail(RR_ERR_INVALID, "rr_merge_topk: null pointer%s");
-  hipError_t e = rr::launch_merge_topk(Din, Iin, nq, m, k, descending, Dout, Iout, (hipStream_t)stream);
+  const rr::MergeSrc src{Din, Iin, m > 0 ? m : 1, 1, 0, 0, 0};
+  hipError_t e = rr::launch_merge_topk(src, nq, m, k, descending, Dout, Iout, (hipStream_t)stream);
   return e == hipSuccess ? RR_OK : hip_fail(e, "rr_merge_topk");
+}
+
+int rr_merge_topk_gathered(const void* gathered, int n_ranks, size_t rank_stride_bytes, size_t ids_offset_bytes, int slots, int nq,
+                           int k_in, int k, int descending, float* Dout, int64_t* Iout, void* stream) {
+  if (n_ranks < 1 || slots < 1 || nq < 0 || k_in < 1 || k < 1) return fail(RR_ERR_INVALID, "rr_merge_topk_gathered: bad sizes%s");
+  const size_t list_elems = (size_t)nq * k_in;
+  if (rank_stride_bytes % 8 != 0 || ids_offset_bytes % 8 != 0 || ids_offset_bytes < (size_t)slots * list_elems * 4 ||
+      rank_stride_bytes < ids_offset_bytes + (size_t)slots * list_elems * 8)
+    return fail(RR_ERR_INVALID, "rr_merge_topk_gathered: the rank stride / id offset do not describe [D f32[slots][nq][k_in] | pad | I i64[slots][nq][k_in]]%s");
+  const long long m = (long long)n_ranks * slots * k_in;
+  if (m > rr::kSelectCap) return fail(RR_ERR_UNSUPPORTED, "rr_merge_topk_gathered: more than 8192 candidates per query%s");
+  if (nq == 0) return RR_OK;
+  if (!gathered || !Dout || !Iout) return fail(RR_ERR_INVALID, "rr_merge_topk_gathered: null pointer%s");
+  if ((uintptr_t)gathered % 8 != 0) return fail(RR_ERR_INVALID, "rr_merge_topk_gathered: the buffer must be 8-byte aligned%s");
+  const rr::MergeSrc src{(const float*)gathered, (const int64_t*)((const char*)gathered + ids_offset_bytes), k_in, slots,
+                         (int64_t)(rank_stride_bytes / 4), (int64_t)(rank_stride_bytes / 8), (int64_t)list_elems};
+  hipError_t e = rr::launch_merge_topk(src, nq, (int)m, k, descending, Dout, Iout, (hipStream_t)stream);
+  return e == hipSuccess ? RR_OK : hip_fail(e, "rr_merge_topk_gathered");
 }
 
 int rr_router_mlp(const rr_router_weights* w, const float* xq, int nq, float* logits, uint8_t* mask, void* stream) {

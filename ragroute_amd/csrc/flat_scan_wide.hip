@@ -331,6 +331,9 @@ RR_MFMA16FI(__bf16, "v_mfma_f32_16x16x32_bf16", bf16x8)
 #ifndef RR_WIDE_ABL
 #define RR_WIDE_ABL 0   // development: timing-only ablations of the step (1 barrier, 2 query loads, 4 DMA, 8 LDS reads, 16 MFMA)
 #endif
+#if RR_WIDE_ABL && !defined(RR_DEV_VARIANTS)
+#error "RR_WIDE_ABL removes work from the step (wrong scores, timing only): RR_DEV_VARIANTS builds only"
+#endif
 template <typename T, bool DENSE, bool L2, int NQB, int PD>
 __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArgs a, const int D) {
   typedef typename Mfma<T>::frag frag;
@@ -657,6 +660,9 @@ __device__ __forceinline__ f32x4 read_acc_fixed128() {
 #ifndef RR_WIDE8_ABL
 #define RR_WIDE8_ABL 0   // development, timing only (wrong results): 8 = every second LDS fragment read skipped, 32 = every query load
 #endif                   // issued twice, 64 = nothing (baseline with the insertion path shut, as the others have it)
+#if RR_WIDE8_ABL && !defined(RR_DEV_VARIANTS)
+#error "RR_WIDE8_ABL removes work from the step (wrong scores, timing only): RR_DEV_VARIANTS builds only"
+#endif
 #ifndef RR_WIDE8_RING
 #define RR_WIDE8_RING 8   // A fragments in flight from LDS per wave
 #endif

@@ -50,8 +50,10 @@ struct FinalizeArgs { float* D; int64_t* I; int64_t id_offset; const uint8_t* ma
 hipError_t launch_compact(const SelectArgs& a, const FinalizeArgs* fin, hipStream_t st);
 hipError_t launch_finalize(const SelectArgs& a, float* D, int64_t* I, int64_t id_offset, const uint8_t* mask, int64_t mask_stride,
                            const void* xq_l2, int dtype, int dim, hipStream_t st);  // xq_l2 != null: emit squared L2 distances
-hipError_t launch_merge_topk(const float* Din, const int64_t* Iin, int nq, int m, int k, int descending,
-                             float* Dout, int64_t* Iout, hipStream_t st);
+// Where the merge reads its candidates: n_outer x n_inner lists of [nq][k_in] (score, id) entries; list (o, i) starts at
+// D + o * outer_D + i * inner (elements), ids likewise with outer_I.  Plain [nq][m] input: one list, k_in = m.
+struct MergeSrc { const float* D; const int64_t* I; int k_in, n_inner; int64_t outer_D, outer_I, inner; };
+hipError_t launch_merge_topk(const MergeSrc& src, int nq, int m, int k, int descending, float* Dout, int64_t* Iout, hipStream_t st);
 
 // prep.hip
 hipError_t launch_l2_normalize_f32(float* x, int64_t n, int64_t d, hipStream_t st);

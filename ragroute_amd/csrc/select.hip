@@ -275,8 +275,12 @@ __global__ __launch_bounds__(256) void finalize_kernel(SelectArgs a, float* D, i
 // ---- cross-source merge (K4) ---------------------------------------------------------------
 // (ord', id) pairs with 64-bit ids: ord' = ord(score) for descending, ~ord(score) for ascending,
 // 0 for padding / NaN.  better(a,b) = a.s > b.s || (a.s == b.s && a.id < b.id).
-__global__ __launch_bounds__(1024) void merge_topk_kernel(const float* Din, const int64_t* Iin, int m, int k,
-                                                          int descending, float* Dout, int64_t* Iout) {
+// Scores compare as IEEE f32: -0.0 == +0.0 (what numpy's argsort of rerank.py:5,30 does), so a zero is keyed as +0.0 and its
+// sign rides in bit 63 of the id slot (valid ids are >= 0), masked in every comparison and restored on output.
+constexpr uint64_t kNegZeroBit = 1ull << 63;
+// Candidate c of query q sits in list c / k_in (lists = n_outer x n_inner blocks of [nq][k_in], see MergeSrc), entry c % k_in:
+// the plain [nq][m] form is one list of k_in = m; the gathered exchange buffer is read where the collective left it.
+__global__ __launch_bounds__(1024) void merge_topk_kernel(const MergeSrc src, int m, int k, int descending, float* Dout, int64_t* Iout) {
   __shared__ uint32_t ss[kSelectCap];
   __shared__ int64_t ids[kSelectCap];
   const uint32_t q = blockIdx.x;
@@ -285,11 +289,15 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const float* Din, cons
     uint32_t s = 0;
     int64_t id = INT64_MAX;
     if (c < m) {
-      const float v = Din[(size_t)q * m + c];
-      const int64_t i = Iin[(size_t)q * m + c];
+      const int list = c / src.k_in, j = c - list * src.k_in;
+      const int o = list / src.n_inner, in = list - o * src.n_inner;
+      const size_t at = (size_t)in * src.inner + (size_t)q * src.k_in + j;
+      const float v = src.D[(size_t)o * src.outer_D + at];
+      const int64_t i = src.I[(size_t)o * src.outer_I + at];
       if (i >= 0 && v == v) {
-        s = descending ? ord_f32(v) : ~ord_f32(v);
-        id = i;
+        const uint32_t o = ord_f32(v == 0.f ? 0.f : v);
+        s = descending ? o : ~o;
+        id = (v == 0.f && (__float_as_uint(v) >> 31)) ? (int64_t)((uint64_t)i | kNegZeroBit) : i;
       }
     }
     ss[c] = s;
@@ -303,11 +311,12 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const float* Din, cons
         const int ixj = i ^ j;
         if (ixj > i) {
           const uint32_t sx = ss[i], sy = ss[ixj];
-          const int64_t ix = ids[i], iy = ids[ixj];
+          const int64_t rx = ids[i], ry = ids[ixj];
+          const int64_t ix = rx & INT64_MAX, iy = ry & INT64_MAX;
           const bool x_worse = sx < sy || (sx == sy && ix > iy);
           const bool desc = (i & k2) == 0;
           if (x_worse == desc && !(sx == sy && ix == iy)) {
-            ss[i] = sy; ss[ixj] = sx; ids[i] = iy; ids[ixj] = ix;
+            ss[i] = sy; ss[ixj] = sx; ids[i] = ry; ids[ixj] = rx;
           }
         }
       }
@@ -320,6 +329,7 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const float* Din, cons
     if (i < np && ss[i] != 0) {
       v = unord_f32(descending ? ss[i] : ~ss[i]);
       id = ids[i];
+      if (id < 0) { v = -0.f; id &= INT64_MAX; }
     }
     Dout[(size_t)q * k + i] = v;
     Iout[(size_t)q * k + i] = id;
@@ -357,9 +367,8 @@ hipError_t launch_finalize(const SelectArgs& a, float* D, int64_t* I, int64_t id
                        (const __bf16*)xq_l2, dim);
   return hipGetLastError();
 }
-hipError_t launch_merge_topk(const float* Din, const int64_t* Iin, int nq, int m, int k, int descending, float* Dout,
-                             int64_t* Iout, hipStream_t st) {
-  hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(1024), 0, st, Din, Iin, m, k, descending, Dout, Iout);
+hipError_t launch_merge_topk(const MergeSrc& src, int nq, int m, int k, int descending, float* Dout, int64_t* Iout, hipStream_t st) {
+  hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(1024), 0, st, src, m, k, descending, Dout, Iout);
   return hipGetLastError();
 }
 

@@ -11,8 +11,7 @@ Everything is enqueued on the current stream; nothing synchronises with the host
 
 The reference's counterpart is the fan-out / gather / concat / rerank of http_server.py:198-209, 227-257, 280-293: one
 message per selected source, replies collected in arrival order, flat candidate lists merged by score."""
-from .rerank import merge_topk
-from .sharded import SHARD_SHIFT, alloc_packed, gather_packed, max_over_ranks
+from .sharded import SHARD_SHIFT, alloc_packed, exchange_packed, max_over_ranks, merge_gathered
 
 
 class RetrievalPipeline:
@@ -67,5 +66,5 @@ class RetrievalPipeline:
             q = xq[sid] if per_shard else xq
             idx.search_prepared(idx.prepare_queries(q), k, id_offset=sid << SHARD_SHIFT, out=(D[slot], I[slot]),
                                 route_mask=None if mask is None else mask[:, sid])
-        Dg, Ig = gather_packed(buf, B, k, self.group, self.slots)
-        return merge_topk(Dg, Ig, k, True)
+        out = exchange_packed(buf, self.group)                       # C1: the ONE collective
+        return merge_gathered(out, B, k, self.slots, k, True)        # K4, reading the gathered buffer where it lies

@@ -1,10 +1,12 @@
 """Cross-source merge — mirror of reference ragroute/rerank.py with the same names and return shapes.
 
-`rerank_medrag` / `rerank_wikipedia` select on the GPU (C ABI `rr_merge_topk`, csrc/select.hip); the
-candidate position is the id, so ties keep the earlier candidate (numpy's argsort leaves tie order
-unspecified, rerank.py:5,30).  `rerank_feb4rag` orders by ground-truth qrels, not by scores
-(rerank.py:12-25): a host dictionary sort, kept as such.
-`merge_topk` is the batched device form used after the multi-GPU candidate all-gather."""
+`rerank_medrag` / `rerank_wikipedia` are HOST functions, as in the reference (its aiohttp front-end calls them on Python
+lists of <= S*k floats, http_server.py:288-293; `north_star`: "host-side rerank merge"): numpy, no HIP context needed.  They
+use the total order the device merge defines (f32 compare, earlier candidate wins a tie — numpy's argsort leaves tie order
+unspecified, rerank.py:5,30).  `rerank_feb4rag` orders by ground-truth qrels, not by scores (rerank.py:12-25): a host
+dictionary sort, kept as such.
+`merge_topk` (C ABI `rr_merge_topk`, csrc/select.hip) is the batched DEVICE form, used where the candidates already are on
+the device: after the multi-GPU candidate all-gather (sharded.py, pipeline.py)."""
 import numpy as np
 import torch
 
@@ -20,8 +22,8 @@ def merge_topk(D, I, k, descending=True):
 
     Contract beyond the reference's one-query list merge (rerank.py:3-9, 28-34):
       * NaN-scored candidates are dropped (treated as padding).  The scan kernels never emit one (a NaN score is never
-        selected), so after the candidate exchange there is nothing to drop; the list-shaped `rerank_medrag` /
-        `rerank_wikipedia` below restore numpy's placement of NaNs on the host.
+        selected), so after the candidate exchange there is nothing to drop; the list-shaped host functions `rerank_medrag`
+        / `rerank_wikipedia` below place NaNs where numpy does.
       * m > 8192 is merged in rounds (per-slice top-k, then a merge of the survivors), which needs k <= 4096."""
     if D.shape != I.shape or D.dim() != 2:
         raise ValueError("merge_topk needs D and I of the same [nq,m] shape")
@@ -41,10 +43,12 @@ def merge_topk(D, I, k, descending=True):
 
 
 def _rerank_by_score(docs, scores, k, descending):
-    """The reference sorts the float64 list with numpy (rerank.py:5, 30).  Here: scores are compared as float32 (what the
-    data sources return: faiss D is f32, data_source.py:187), candidate position is the tie-break (earlier first; numpy's
-    default sort leaves ties unspecified), and NaN scores are placed where numpy's argsort puts them — at the END of the
-    ascending order: `[::-1]` therefore ranks them FIRST for rerank_medrag, rerank_wikipedia keeps them last."""
+    """The reference sorts the float64 list with numpy on the HOST (rerank.py:5, 30; called from the aiohttp front-end,
+    http_server.py:288-293), and so does this: a <= 128-element sort needs no HIP context in the front-end process.
+    The order is the one `rr_merge_topk` defines, restated in numpy: scores are compared as float32 (what the data sources
+    return: faiss D is f32, data_source.py:187), candidate position is the tie-break (earlier first; numpy's default sort
+    leaves ties unspecified), and NaN scores are placed where numpy's argsort puts them — at the END of the ascending order:
+    `[::-1]` therefore ranks them FIRST for rerank_medrag, rerank_wikipedia keeps them last."""
     n = len(scores)
     if n == 0:
         return [], []
@@ -53,17 +57,13 @@ def _rerank_by_score(docs, scores, k, descending):
     if k <= 0:
         return [], []
     s32 = np.asarray(scores, np.float64).astype(np.float32)
-    nan_pos = np.flatnonzero(np.isnan(s32))
-    head = [int(i) for i in nan_pos[::-1][:k]] if descending else []      # reversed tail of the ascending order
-    want = min(k, n) - len(head)
-    order = []
-    if want > 0 and n - len(nan_pos) > 0:
-        D = torch.from_numpy(s32[None, :]).to("cuda")
-        I = torch.arange(n, dtype=torch.int64, device="cuda")[None, :]
-        _, o = merge_topk(D, I, want, descending)
-        order = [i for i in o[0].cpu().tolist() if i >= 0]
-    tail = [] if descending else [int(i) for i in nan_pos[: max(0, min(k, n) - len(order))]]
-    order = head + order + tail
+    nan = np.isnan(s32)
+    nan_pos = np.flatnonzero(nan)
+    valid = np.flatnonzero(~nan)
+    v = s32[valid]
+    ranked = valid[np.lexsort((valid, -v if descending else v))]      # IEEE f32 compare (-0.0 == 0.0); the earlier candidate wins a tie
+    order = (list(nan_pos[::-1]) + list(ranked)) if descending else (list(ranked) + list(nan_pos))
+    order = [int(i) for i in order[:k]]
     return [docs[i] for i in order], [scores[i] for i in order]
 
 

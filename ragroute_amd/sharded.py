@@ -63,27 +63,61 @@ def alloc_packed(B, k, device, slots=1):
     return (buf, D[0], I[0]) if slots == 1 else (buf, D, I)
 
 
-def gather_packed(buf, B, k, group=None, slots=1):
-    """all_gather of packed candidate buffers (see alloc_packed) -> ([B, G*slots*k] scores, [B, G*slots*k] ids); columns are
-    rank-major, then slot-major: rank r's shard slot s occupies columns (r*slots + s)*k .. +k."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+def packed_layout(B, k, slots=1):
+    """(bytes of the D region, offset of the I region, bytes per rank) of a packed candidate buffer (alloc_packed)."""
     nD = slots * B * k * 4
     pad = (-nD) % 8
+    return nD, nD + pad, nD + pad + slots * B * k * 8
+
+
+def exchange_packed(buf, group=None):
+    """THE collective of the path: all_gather of every rank's packed candidate buffer -> uint8 [world, bytes per rank], left
+    exactly as the collective wrote it (`merge_gathered` reads it in place).  One rank: a view of `buf`, nothing is copied."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
-        out = buf.view(1, buf.numel())
-    elif buf.is_cuda and dist.get_backend(group) == "gloo":  # rehearsal on one box: stage through the host
+        return buf.view(1, buf.numel())
+    if buf.is_cuda and dist.get_backend(group) == "gloo":  # rehearsal on one box: stage through the host
         out = torch.empty(world * buf.numel(), dtype=torch.uint8)
         dist.all_gather_into_tensor(out, buf.cpu(), group=group)
-        out = out.to(buf.device).view(world, buf.numel())
-    else:
-        out = torch.empty(world * buf.numel(), dtype=torch.uint8, device=buf.device)
-        dist.all_gather_into_tensor(out, buf, group=group)
-        out = out.view(world, buf.numel())
+        return out.to(buf.device).view(world, buf.numel())
+    out = torch.empty(world * buf.numel(), dtype=torch.uint8, device=buf.device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    return out.view(world, buf.numel())
+
+
+def unpack_gathered(out, B, k, slots=1):
+    """Views / copies of an exchanged buffer as ([B, G*slots*k] scores, [B, G*slots*k] ids); columns are rank-major, then
+    slot-major: rank r's shard slot s occupies columns (r*slots + s)*k .. +k.  This is the layout statement the tests check
+    the in-place device merge against; the product path does not call it on the GPU (it costs four copy kernels)."""
+    world = out.shape[0]
+    nD, ioff, _ = packed_layout(B, k, slots)
     if world == 1 and slots == 1:
-        return out[0, :nD].view(torch.float32).view(B, k), out[0, nD + pad:].view(torch.int64).view(B, k)
+        return out[0, :nD].view(torch.float32).view(B, k), out[0, ioff:].view(torch.int64).view(B, k)
     Dg = out[:, :nD].contiguous().view(torch.float32).view(world * slots, B, k).permute(1, 0, 2).reshape(B, world * slots * k)
-    Ig = out[:, nD + pad:].contiguous().view(torch.int64).view(world * slots, B, k).permute(1, 0, 2).reshape(B, world * slots * k)
+    Ig = out[:, ioff:].contiguous().view(torch.int64).view(world * slots, B, k).permute(1, 0, 2).reshape(B, world * slots * k)
     return Dg, Ig
+
+
+def gather_packed(buf, B, k, group=None, slots=1):
+    """exchange_packed + unpack_gathered (see there)."""
+    return unpack_gathered(exchange_packed(buf, group), B, k, slots)
+
+
+def merge_gathered(out, B, k_in, slots, k, descending=True):
+    """Cross-source merge (rerank.py:3-9 over the concatenation of http_server.py:280-286) of an exchanged buffer, read in
+    place by `rr_merge_topk_gathered`: no repacking between the collective and the merge.  Fresh (D f32 [B,k], I i64 [B,k])."""
+    from ._lib import check, lib
+    world = out.shape[0]
+    _, ioff, per_rank = packed_layout(B, k_in, slots)
+    if world * slots * k_in > 8192:   # beyond one LDS sort: fall back to the staged merge of the unpacked view
+        from .rerank import merge_topk
+        Dg, Ig = unpack_gathered(out, B, k_in, slots)
+        return merge_topk(Dg, Ig, k, descending)
+    Do = torch.empty((B, k), dtype=torch.float32, device=out.device)
+    Io = torch.empty((B, k), dtype=torch.int64, device=out.device)
+    check(lib().rr_merge_topk_gathered(out.data_ptr(), world, per_rank, ioff, slots, B, k_in, k, int(bool(descending)),
+                                       Do.data_ptr(), Io.data_ptr(), torch.cuda.current_stream().cuda_stream), "rr_merge_topk_gathered")
+    return Do, Io
 
 
 def max_over_ranks(value, device, group=None):
@@ -126,9 +160,8 @@ class ShardedFlatSearch:
 
     def search(self, xq_half, k, route_mask=None):
         """Full federated step on device: local scans -> ONE all_gather -> merge.  Every rank gets the result."""
-        from .rerank import merge_topk
         buf, _, _ = self.local_candidates(xq_half, k, route_mask)
-        Dg, Ig = gather_packed(buf, xq_half.shape[0], k, self.group, self.slots)
-        if Dg.shape[1] == k and route_mask is None:
-            return Dg, Ig
-        return merge_topk(Dg, Ig, k, True)
+        out = exchange_packed(buf, self.group)
+        # always through the merge: it writes fresh tensors (the packed buffer is reused by the next search, so returning
+        # views of it would let search N+1 overwrite what the caller still holds of search N)
+        return merge_gathered(out, xq_half.shape[0], k, self.slots, k, True)

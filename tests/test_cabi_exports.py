@@ -44,10 +44,27 @@ def test_argument_validation_without_gpu():
     assert L.rr_flat_search(None, 0, 10, 768, None, 0, 5, None, None, 0, None, 0, None, 0, None) == 0       # nq = 0 is a no-op
     assert L.rr_merge_topk(None, None, 1, 9000, 5, 1, None, None, None) == -2
     assert L.rr_merge_topk(None, None, 0, 5, 5, 1, None, None, None) == 0
+    # rr_merge_topk_gathered: [rank][D f32[slots][nq][k_in] | pad | I i64[slots][nq][k_in]]
+    assert L.rr_merge_topk_gathered(None, 8, 256 * 32 * 12, 256 * 32 * 4, 1, 256, 32, 32, 1, None, None, None) == -1     # null buffer
+    assert L.rr_merge_topk_gathered(None, 8, 256 * 32 * 12, 256 * 32 * 4, 1, 0, 32, 32, 1, None, None, None) == 0        # nq = 0
+    assert L.rr_merge_topk_gathered(None, 8, 256 * 32 * 12 + 4, 256 * 32 * 4, 1, 256, 32, 32, 1, None, None, None) == -1  # stride not 8-aligned
+    assert L.rr_merge_topk_gathered(None, 8, 256 * 32 * 12, 256 * 32 * 2, 1, 256, 32, 32, 1, None, None, None) == -1     # ids overlap the scores
+    assert L.rr_merge_topk_gathered(None, 8, 256 * 32 * 8, 256 * 32 * 4, 1, 256, 32, 32, 1, None, None, None) == -1      # rank block too short
+    assert L.rr_merge_topk_gathered(None, 100, 256 * 100 * 12, 256 * 100 * 4, 1, 256, 100, 10, 1, None, None, None) == -2  # > 8192 candidates
     assert L.rr_rows_to_half(None, 1, 8, 4, None, 0, 8, 0, None) == -1
     assert L.rr_l2_normalize_f32(None, 0, 8, None) == 0
     assert L.rr_router_mlp(None, None, 1, None, None, None) == -1
     assert L.rr_flat_search_workspace_bytes(0) == 0
+
+
+def test_library_under_test_is_a_product_build():
+    """rr_build_flags(): no -D switch, i.e. neither the development kernels nor the timing-only ablations (which produce wrong
+    scores) are compiled in; RR_LIB_OVERRIDE (A/B libraries) must not be set when the suite runs."""
+    from ragroute_amd import _build, _lib
+    assert not os.environ.get("RR_LIB_OVERRIDE")
+    flags = _lib.lib().rr_build_flags().decode()
+    assert flags == " ".join(_build.PRODUCT_FLAGS), flags
+    assert "-D" not in flags
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from tests.util import synth_router_case
 
 
@@ -177,3 +179,72 @@ def test_compat_shim_resolves_hot_path_modules_to_ragroute_amd():
         env.pop("RAGROUTE_REFERENCE_DIR", None)
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert res.returncode == 0 and "shim ok" in res.stdout, res.stderr[-1500:]
+
+
+# ---- list-shaped merges run on the HOST, like the reference's (rerank.py:3-9, 28-34; called from http_server.py:288-293) ----
+def test_rerank_functions_match_reference_golden_on_the_host():
+    from ragroute_amd import rerank as R
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rerank.json")))
+    for c in g["cases"]:
+        assert list(map(list, R.rerank_medrag(c["docs"], c["scores"], c["k"]))) == c["medrag"]
+        assert list(map(list, R.rerank_wikipedia(c["docs"], c["scores"], c["k"]))) == c["wikipedia"]
+    t = g["ties"]
+    docs, scores = R.rerank_medrag(t["docs"], t["scores"], t["k"])
+    assert scores == t["medrag_scores"] and docs[:2] == ["b", "d"]
+    assert R.rerank_medrag([], [], 5) == ([], []) and R.rerank_wikipedia([], [], 5) == ([], [])
+
+
+def test_rerank_nan_and_long_lists_follow_numpy():
+    """rerank.py:5 is `np.argsort(scores)[::-1][:k]`, rerank.py:30 `np.argsort(scores)[:k]`: numpy sorts NaN to the END of the
+    ascending order, so rerank_medrag ranks a NaN-scored document FIRST and rerank_wikipedia keeps it last.  Lists of any length."""
+    from ragroute_amd.rerank import rerank_medrag, rerank_wikipedia
+    rng = np.random.default_rng(12)
+    scores = rng.permutation(40).astype(np.float64).tolist()       # tie-free
+    scores[17] = float("nan")
+    docs = [f"d{i}" for i in range(40)]
+    for k in (1, 5, 39, 40, 64):
+        order = np.argsort(scores)[::-1][:k]
+        d, s = rerank_medrag(docs, scores, k)
+        assert d == [docs[i] for i in order]
+        assert [x for x in s if x == x] == [scores[i] for i in order if scores[i] == scores[i]] and (s[0] != s[0])
+        order = np.argsort(scores)[:k]
+        d, s = rerank_wikipedia(docs, scores, k)
+        assert d == [docs[i] for i in order]
+    n = 20_000
+    scores = rng.permutation(n).astype(np.float64).tolist()
+    docs = list(range(n))
+    d, s = rerank_medrag(docs, scores, 32)
+    order = np.argsort(scores)[::-1][:32]
+    assert d == order.tolist() and s == [scores[i] for i in order]
+    d, s = rerank_wikipedia(docs, scores, 100)
+    assert d == np.argsort(scores)[:100].tolist()
+
+
+def test_host_rerank_uses_the_device_merges_total_order():
+    """Same candidates, same order as `rr_merge_topk` defines it (restated by the oracle's merge): f32 compare, the earlier
+    candidate wins a tie, -0.0 == +0.0; the scores come back as the caller's own objects."""
+    from oracle import oracle as O
+    from ragroute_amd.rerank import rerank_medrag, rerank_wikipedia
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        n, k = int(rng.integers(1, 300)), int(rng.integers(1, 140))
+        sc = (np.round(rng.standard_normal(n) * 3) / 3).tolist()    # many ties, and both zeros
+        docs = list(range(n))
+        for desc, f in ((True, rerank_medrag), (False, rerank_wikipedia)):
+            Dr, Ir = O.merge_topk(np.asarray(sc, np.float32)[None], np.arange(n, dtype=np.int64)[None], min(k, n), desc)
+            d, s = f(docs, sc, k)
+            assert d == Ir[0].tolist() and s == [sc[i] for i in d]
+
+
+def test_list_rerank_needs_no_gpu():
+    """The front-end process (http_server.py:25) imports these and must not need a HIP context for a 128-element sort."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import torch\n"
+            "torch.cuda.is_available = lambda: (_ for _ in ()).throw(AssertionError('the list rerank touched the GPU'))\n"
+            "torch.Tensor.cuda = None\n"
+            "from ragroute_amd.rerank import rerank_medrag, rerank_wikipedia\n"
+            "assert rerank_medrag(list('abcdefgh'), [.1,.9,.5,.9,.3,.2,.7,.5], 4) == (['b','d','g','c'], [0.9,0.9,0.7,0.5])\n"
+            "assert rerank_wikipedia(list('abcdefgh'), [.1,.9,.5,.9,.3,.2,.7,.5], 4) == (['a','f','e','c'], [0.1,0.2,0.3,0.5])\n") % ROOT
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, HIP_VISIBLE_DEVICES="-1"))

@@ -1,7 +1,8 @@
 """The reference's UNMODIFIED `main.py` (BASELINE config 0's plumbing) started with the compat shim on PYTHONPATH: its orchestrator
 (ragroute/ragroute.py:43-54) spawns `run_router` / `run_data_source` from ragroute_amd, its own aiohttp front-end
 (ragroute/http_server.py) talks to them over the wire format, and a `GET /query` comes back with the merged documents.
-`--simulate` (main.py:17) needs no models, indexes or GPU.  pyzmq / ollama / python-liquid are not in this image: transport is
+`--simulate` (main.py:17) needs no models, indexes or GPU — and since round 3 neither does the front-end's merge: the list-shaped
+`rerank_medrag` is a host function as in the reference, so the query COMPLETES in the build container.  pyzmq / ollama / python-liquid are not in this image: transport is
 a TCP stand-in (tests/stubs_tcp/zmq), the two generation-side imports are inert stubs.  Runs only where the reference checkout
 is mounted (never on the GPU box)."""
 import json
@@ -42,13 +43,11 @@ def test_reference_main_py_runs_unchanged_with_the_drop_ins(tmp_path):
                              "--disable-llm", "--simulate"], cwd=str(tmp_path), env=env, stdout=log, stderr=subprocess.STDOUT,
                             start_new_session=True)
     try:
-        import torch
-        have_gpu = torch.cuda.is_available()
         url = "http://127.0.0.1:8000/query?" + urllib.parse.urlencode({"q": "what is aspirin?", "choices": json.dumps(["a", "b"]), "qid": "q1"})
         body, deadline = None, time.time() + 90
         while time.time() < deadline and proc.poll() is None:
             try:
-                with urllib.request.urlopen(url, timeout=60 if have_gpu else 12) as r:
+                with urllib.request.urlopen(url, timeout=60) as r:
                     body = json.loads(r.read())
                 break
             except OSError as e:
@@ -56,17 +55,15 @@ def test_reference_main_py_runs_unchanged_with_the_drop_ins(tmp_path):
                 if refused:                       # the front-end is not up yet
                     time.sleep(0.5)
                     continue
-                break                             # timed out: without a GPU the merge raises and the query never completes
+                break                             # timed out
         logtxt = open(tmp_path / "main.log").read()
         # the reference's front-end gathered one reply per data source, each produced by ragroute_amd.data_source (http_server.py:233-257)
         for name in ("pubmed", "statpearls", "textbooks", "wikipedia"):
             assert f"Received results from data source {name}" in logtxt, logtxt[-3000:]
-        if have_gpu:
-            # ... and its _complete_query (267-341) merged them with ragroute_amd.rerank.rerank_medrag and answered
-            assert body is not None and "Document 1 content" in json.dumps(body), body
-        else:
-            # no GPU here: the merge is the HIP kernel and there is NO CPU fallback - the front-end's call reaches it and fails loudly
-            assert "ragroute_amd/rerank.py" in logtxt and "No HIP GPUs are available" in logtxt, logtxt[-3000:]
+        # ... and its _complete_query (267-341) merged them with ragroute_amd.rerank.rerank_medrag (a host function, as in the
+        # reference: no HIP device in this process) and answered
+        assert body is not None and "Document 1 content" in json.dumps(body), (body, logtxt[-3000:])
+        assert "No HIP GPUs are available" not in logtxt
     finally:
         if proc.poll() is None:
             os.killpg(proc.pid, signal.SIGINT)

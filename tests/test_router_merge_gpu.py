@@ -85,15 +85,67 @@ def test_merge_topk_vs_oracle(gpu):
             assert np.array_equal(Ig.cpu().numpy(), Ir) and np.array_equal(Dg.cpu().numpy(), Dr)
 
 
-def test_rerank_functions_match_reference_golden(gpu):
-    from ragroute_amd import rerank as R
-    g = json.load(open(os.path.join(GOLD, "rerank.json")))
-    for c in g["cases"]:
-        assert list(map(list, R.rerank_medrag(c["docs"], c["scores"], c["k"]))) == c["medrag"]
-        assert list(map(list, R.rerank_wikipedia(c["docs"], c["scores"], c["k"]))) == c["wikipedia"]
-    t = g["ties"]
-    docs, scores = R.rerank_medrag(t["docs"], t["scores"], t["k"])
-    assert scores == t["medrag_scores"] and docs[:2] == ["b", "d"]
+def test_merge_compares_zeros_as_ieee_and_keeps_their_sign(gpu):
+    """-0.0 == +0.0 for the merge (numpy's argsort of rerank.py:5,30 and the oracle compare floats, not bit patterns): ties between
+    them go by ascending id, and each candidate keeps its own sign bit on output."""
+    from oracle import oracle as O
+    from ragroute_amd.rerank import merge_topk
+    D = np.array([[0.0, -0.0, -0.0, 0.0, -1.0, 0.0, -0.0, 1.0]], np.float32)
+    I = np.array([[50, 10, 40, 20, 5, 30, 60, 70]], np.int64)
+    for desc in (True, False):
+        Dg, Ig = merge_topk(torch.from_numpy(D).cuda(), torch.from_numpy(I).cuda(), 8, desc)
+        Dr, Ir = O.merge_topk(D, I, 8, desc)
+        assert np.array_equal(Ig.cpu().numpy(), Ir)
+        assert Dg.cpu().numpy().tobytes() == Dr.tobytes()
+
+
+def test_merge_gathered_reads_the_exchange_buffer_in_place(gpu):
+    """rr_merge_topk_gathered on a buffer laid out as the all-gather leaves it ([rank][D f32[slots][B][k] | pad | I i64[slots][B][k]])
+    against the layout statement (sharded.unpack_gathered) + the oracle's merge; odd B*k*slots exercises the 8-byte pad."""
+    from oracle import oracle as O
+    from ragroute_amd import sharded as S
+    rng = np.random.default_rng(5)
+    for world, slots, B, k_in, k in [(1, 1, 256, 32, 32), (8, 1, 256, 32, 32), (3, 2, 7, 5, 9), (2, 3, 1, 1, 4), (8, 2, 256, 100, 100), (4, 1, 33, 64, 10)]:
+        bufs = []
+        for r in range(world):
+            buf, D, I = S.alloc_packed(B, k_in, gpu, slots)
+            D = D.view(slots, B, k_in)
+            I = I.view(slots, B, k_in)
+            D.copy_(torch.from_numpy(np.round(rng.standard_normal((slots, B, k_in)) * 3).astype(np.float32) / 3))   # ties across ranks
+            I.copy_(torch.from_numpy(rng.permutation(slots * B * k_in).reshape(slots, B, k_in).astype(np.int64) + (r << 40)))
+            if r == world - 1:
+                I[slots - 1, :, k_in // 2:] = -1          # a short source: padding entries
+                D[slots - 1, :, k_in // 2:] = float("-inf")
+            bufs.append(buf)
+        out = torch.stack(bufs)                          # what all_gather_into_tensor writes: [world, bytes per rank]
+        assert out.shape[1] == S.packed_layout(B, k_in, slots)[2]
+        for desc in (True, False):
+            Dg, Ig = S.merge_gathered(out, B, k_in, slots, k, desc)
+            Dl, Il = S.unpack_gathered(out, B, k_in, slots)
+            Dr, Ir = O.merge_topk(Dl.cpu().numpy(), Il.cpu().numpy(), k, desc)
+            assert np.array_equal(Ig.cpu().numpy(), Ir) and np.array_equal(Dg.cpu().numpy(), Dr), (world, slots, B, k_in, k, desc)
+
+
+def test_sharded_search_results_do_not_alias_the_reused_exchange_buffer(gpu):
+    """ShardedFlatSearch reuses its packed candidate buffer; what search N returned must still be search N's after search N+1
+    (one rank, one shard, no mask: the case that used to return views of that buffer)."""
+    from oracle import oracle as O
+    from ragroute_amd.flat_index import FlatIndex
+    from ragroute_amd.sharded import ShardedFlatSearch
+    rng = np.random.default_rng(9)
+    xb = int_data(rng, 20_000, 128)
+    idx = FlatIndex(128, device=gpu)
+    idx.add(xb)
+    sh = ShardedFlatSearch([idx], [3])
+    q1, q2 = int_data(rng, 16, 128), int_data(rng, 16, 128)
+    D1, I1 = sh.search(idx.prepare_queries(q1), 10)
+    keep_D, keep_I = D1.clone(), I1.clone()
+    D2, I2 = sh.search(idx.prepare_queries(q2), 10)
+    torch.cuda.synchronize()
+    assert torch.equal(D1, keep_D) and torch.equal(I1, keep_I)
+    assert D1.data_ptr() != D2.data_ptr()
+    Dr, Ir = O.flat_search_ip(xb, q1, 10)
+    assert np.array_equal(I1.cpu().numpy(), Ir + (3 << 40)) and np.array_equal(D1.cpu().numpy(), Dr)
 
 
 def test_normalize_l2_and_ingest(gpu):
@@ -322,33 +374,6 @@ def test_torch_router_op_equals_router_class(gpu):
     l2, m2 = torch.ops.ragroute.router_mlp(xq, t["w1q"], t["c1"], t["ln1_g"], t["ln1_b"], t["w2"], t["b2"], t["ln2_g"], t["ln2_b"], t["w3"],
                                            t["model_of_source"], float(np.asarray(sd["fc3.bias"]).reshape(-1)[0]), r._folded.struct.prob_threshold)
     assert torch.equal(l2, logits) and torch.equal(m2, mask)
-
-
-def test_rerank_nan_and_long_lists_follow_numpy(gpu):
-    """rerank.py:5 is `np.argsort(scores)[::-1][:k]`, rerank.py:30 `np.argsort(scores)[:k]`: numpy sorts NaN to the END of the
-    ascending order, so rerank_medrag ranks a NaN-scored document FIRST and rerank_wikipedia keeps it last.  Also lists longer
-    than one device merge (8192 candidates), which the reference handles like any other length."""
-    from ragroute_amd.rerank import rerank_medrag, rerank_wikipedia
-    rng = np.random.default_rng(12)
-    scores = rng.permutation(40).astype(np.float64).tolist()       # tie-free
-    scores[17] = float("nan")
-    docs = [f"d{i}" for i in range(40)]
-    for k in (1, 5, 39, 40, 64):
-        order = np.argsort(scores)[::-1][:k]
-        d, s = rerank_medrag(docs, scores, k)
-        assert d == [docs[i] for i in order]
-        assert [x for x in s if x == x] == [scores[i] for i in order if scores[i] == scores[i]] and (s[0] != s[0])
-        order = np.argsort(scores)[:k]
-        d, s = rerank_wikipedia(docs, scores, k)
-        assert d == [docs[i] for i in order]
-    n = 20_000                                                     # > 8192 candidates: merged in rounds
-    scores = rng.permutation(n).astype(np.float64).tolist()
-    docs = list(range(n))
-    d, s = rerank_medrag(docs, scores, 32)
-    order = np.argsort(scores)[::-1][:32]
-    assert d == order.tolist() and s == [scores[i] for i in order]
-    d, s = rerank_wikipedia(docs, scores, 100)
-    assert d == np.argsort(scores)[:100].tolist()
 
 
 def test_data_source_serves_an_l2_index_wider_than_768(gpu, tmp_path, monkeypatch):

@@ -102,10 +102,15 @@ def _config4_worker(rank, world, port, out_dir, layout):
     try:
         from oracle import oracle as O
         from ragroute_amd import pipeline as P
-        from ragroute_amd.sharded import SHARD_SHIFT
+        from ragroute_amd.sharded import SHARD_SHIFT, unpack_gathered
         from tests.util import int_data
-        # the device merge needs a GPU: stand it in with the oracle's merge (same contract), the exchange layout is what is checked
-        P.merge_topk = lambda D, I, k, desc: tuple(torch.from_numpy(a) for a in O.merge_topk(D.numpy(), I.numpy(), k, desc))
+        # the device merge (rr_merge_topk_gathered reads the exchanged buffer in place) needs a GPU: stand it in with the layout
+        # statement + the oracle's merge (same contract); the exchange and its layout are what is checked here, the kernel's
+        # reading of the same buffer is checked on the GPU (test_router_merge_gpu.py::test_merge_gathered_reads_the_exchange_buffer_in_place)
+        def merge_gathered_cpu(out, B, k_in, slots, k, descending=True):
+            Dg, Ig = unpack_gathered(out, B, k_in, slots)
+            return tuple(torch.from_numpy(a) for a in O.merge_topk(Dg.numpy(), Ig.numpy(), k, descending))
+        P.merge_gathered = merge_gathered_cpu
         rng = np.random.default_rng(7)  # same stream on both ranks
         widths = {0: 768, 1: 1024, 2: 4096, 3: 768}            # FeB4RAG-shaped: config.py:45-57, 92-96
         rows = {0: 500, 1: 333, 2: 260, 3: 41}
