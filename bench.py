@@ -9,9 +9,14 @@ candidates] -> cross-shard merge (K4).  One process per GPU.
 
   --scaling weak   (default) every rank holds its own 10M-row shard and every query is answered against all N
                    shards: the whole job performs N x 256 query-shard searches per step, `value` = N*256*K/t
-                   (at N=1 exactly queries/sec on one 10M shard — the BASELINE configuration).
-  --scaling strong SURVEY.md §8e: the federation is fixed at --total-shards (8) x 10M rows; rank r holds shards
-                   r, r+N, ...; `value` = 256*K/t = queries/sec against the whole 80M-row federation.
+                   = (query x shard) PAIRS per second (at N=1 exactly queries/sec on one 10M shard — the BASELINE
+                   configuration).  By construction `value` grows ~N x while the exchange stays cheap; the number that
+                   does not is `federation_queries_per_sec` = 256*K/t, queries answered per second against the whole
+                   N-shard federation, printed beside it.
+  --scaling strong SURVEY.md §8e (the >= 6x target): the federation is fixed at --total-shards (8) x 10M rows; rank r
+                   holds shards r, r+N, ...; `value` = `federation_queries_per_sec` = 256*K/t.
+Every line also carries `exchange_ms` / `merge_ms` (HIP events around the all_gather and the merge, mean per step on rank 0)
+and `rccl_ranks` (dist.get_world_size() after init_process_group; 1 without a process group).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -184,7 +189,9 @@ def main():
         launch (rr_profile_*), and optionally one HIP-event pair per step on the launch stream."""
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)] if with_events else []
         fence()
-        check(lib().rr_profile_begin(n_steps * 8 * len(shards) + 8), "rr_profile_begin")
+        # scan launches per shard and step: bootstrap + up to 8 chunks (capi.hip chunk_schedule), per 256-query block;
+        # rr_profile_end FAILS if a launch went unrecorded, so the roofline cannot be overstated by a short buffer
+        check(lib().rr_profile_begin(n_steps * 10 * len(shards) * (-(-B // 256)) + 16), "rr_profile_begin")
         t0 = time.perf_counter()
         for i in range(n_steps):
             if with_events:
@@ -206,6 +213,14 @@ def main():
     for _ in range(args.warmup):
         step()
     elapsed, scan_ms, n_launch, per_step = timed(args.steps, True)
+    # exchange / merge time per step: a few extra steps AFTER the timed region (the three event records per step stay out of `value`)
+    pipe.time_stages(True)
+    for _ in range(min(10, max(3, args.steps))):
+        step()
+    exchange_ms, merge_ms = pipe.stage_ms()
+    pipe.time_stages(False)
+    fence()
+    rccl_ranks = dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1
 
     sustained = None
     if args.sustained_seconds > 0:
@@ -238,14 +253,18 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "median_ms": round(percentile(per_step, 0.5), 4), "p10_ms": round(percentile(per_step, 0.1), 4),
             "p90_ms": round(percentile(per_step, 0.9), 4),
+            "federation_queries_per_sec": round(B * K / elapsed, 1), "exchange_ms": round(exchange_ms, 4), "merge_ms": round(merge_ms, 4),
+            "rccl_ranks": rccl_ranks, "exchange_backend": (backend if world > 1 else "none (one rank: the merge reads the local buffer)"),
             "config": {"workload": f"{shape}, {layout}, query batch {B}, k={k}, exact inner-product top-k + router MLP over "
                                    f"{C} source(s) + cross-shard merge",
                        "rows_per_shard": n, "dim": d, "batch": B, "k": k, "shards_total": C, "shards_per_gpu": S,
                        "parallelism": f"shard-per-gpu x{world}" if not strong else f"{C} shards over {world} gpu(s)",
-                       "unit_definition": ("queries per second against the whole fixed federation" if strong else
-                                           "query x 10M-row shard searches per second, whole job (N=1: queries/sec on one shard)"),
+                       "unit_definition": ("queries per second against the whole fixed federation (= federation_queries_per_sec)" if strong else
+                                           f"(query x {n}-row shard) PAIRS searched per second, whole job = N x federation_queries_per_sec "
+                                           "(N=1: queries/sec on one shard, the BASELINE configuration); federation_queries_per_sec = "
+                                           "queries answered per second against all N shards"),
                        "timing": "ms_per_step = wall clock of the K steps between fences / K; median/p10/p90 = one HIP-event pair per step"},
-            "roofline": {"bound": "hbm", "kernel": "flat_scan16_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": lib().rr_flat_scan_kernel_name(shards[0].dim, B).decode(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": round(alg_bytes / launches_per_step),
                          "avg_launch_ms": round(scan_ms / max(1, n_launch), 4), "launches_per_step": round(launches_per_step, 2),

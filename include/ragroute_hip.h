@@ -122,7 +122,11 @@ int rr_flat_search_screened(const void* d_xb, int dtype, const void* d_x8, const
  * corpus rows they covered.  No reference counterpart (the reference only has time.time() deltas,
  * data_source.py:104,130). */
 int rr_profile_begin(int max_launches);
+/* RR_ERR_WORKSPACE (after filling the outputs with what WAS recorded) if more than max_launches launches were made. */
 int rr_profile_end(double* scan_ms_total, int* n_launches, double* rows_scanned);
+/* Name of the scan kernel rr_flat_search dispatches the filter launches of a (dim, nq-query block) search to — the kernel
+ * `roofline` figures refer to; "" if dim is not a padded dim. */
+const char* rr_flat_scan_kernel_name(int dim, int nq);
 
 /* Cross-source candidate merge: per query, the k best of m (score, id) candidates.
  * Replaces `np.argsort(scores)[::-1][:k]` / `np.argsort(scores)[:k]` — reference

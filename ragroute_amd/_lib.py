@@ -15,7 +15,7 @@ EXPORTS = ("rr_version", "rr_last_error", "rr_device_cus", "rr_padded_dim", "rr_
            "rr_flat_search_workspace_bytes", "rr_flat_search", "rr_merge_topk", "rr_router_mlp", "rr_profile_begin",
            "rr_profile_end", "rr_centroid", "rr_flat_search_l2", "rr_half_sqnorms", "rr_screen_dim", "rr_screen_build",
            "rr_flat_search_screened_workspace_bytes", "rr_flat_search_screened", "rr_router_workspace_bytes", "rr_router_mlp_ws",
-           "rr_build_flags", "rr_merge_topk_gathered")
+           "rr_build_flags", "rr_merge_topk_gathered", "rr_flat_scan_kernel_name")
 
 
 class RouterWeightsStruct(ctypes.Structure):
@@ -58,6 +58,8 @@ def lib():
         L.rr_merge_topk.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
         L.rr_merge_topk_gathered.argtypes = [vp, i32, sz, sz, i32, i32, i32, i32, i32, vp, vp, vp]
         L.rr_build_flags.restype = ctypes.c_char_p
+        L.rr_flat_scan_kernel_name.argtypes = [i32, i32]
+        L.rr_flat_scan_kernel_name.restype = ctypes.c_char_p
         L.rr_router_mlp.argtypes = [ctypes.POINTER(RouterWeightsStruct), vp, i32, vp, vp, vp]
         L.rr_router_workspace_bytes.argtypes = [ctypes.POINTER(RouterWeightsStruct), i32]
         L.rr_router_workspace_bytes.restype = sz

@@ -39,9 +39,10 @@ int device_cus() {
 // ---- live profiling of the dominant kernel (bench.py roofline) -------------------------------------
 struct ProfEntry { hipEvent_t start, stop; uint64_t rows; };
 thread_local ProfEntry* g_prof = nullptr;
-thread_local int g_prof_cap = 0, g_prof_n = 0;
+thread_local int g_prof_cap = 0, g_prof_n = 0, g_prof_dropped = 0;
 
 hipError_t profiled_scan(const rr::ScanArgs& a, int dtype, int D, bool dense, int grid, hipStream_t st) {
+  if (g_prof && g_prof_n >= g_prof_cap) ++g_prof_dropped;   // rr_profile_end reports it: a silent drop would overstate the roofline
   if (g_prof && g_prof_n < g_prof_cap) {
     ProfEntry& p = g_prof[g_prof_n++];
     p.rows = (uint64_t)a.n_tiles * rr::kTileRows;
@@ -362,6 +363,7 @@ int rr_profile_begin(int max_launches) {
   g_prof = new ProfEntry[max_launches];
   g_prof_cap = 0;
   g_prof_n = 0;
+  g_prof_dropped = 0;
   for (int i = 0; i < max_launches; ++i) {
     if (hipEventCreate(&g_prof[i].start) != hipSuccess || hipEventCreate(&g_prof[i].stop) != hipSuccess)
       return fail(RR_ERR_HIP, "rr_profile_begin: hipEventCreate failed%s");
@@ -387,7 +389,18 @@ int rr_profile_end(double* scan_ms_total, int* n_launches, double* rows_scanned)
   if (scan_ms_total) *scan_ms_total = ms;
   if (n_launches) *n_launches = n;
   if (rows_scanned) *rows_scanned = rows;
+  if (g_prof_dropped > 0) {
+    char msg[32];
+    snprintf(msg, sizeof(msg), "%d", g_prof_dropped);
+    g_prof_dropped = 0;
+    return fail(RR_ERR_WORKSPACE, "rr_profile_end: %s scan launches were not recorded (max_launches of rr_profile_begin too small); the totals returned are incomplete", msg);
+  }
   return RR_OK;
+}
+
+const char* rr_flat_scan_kernel_name(int dim, int nq) {
+  if (rr::scan_padded_dim(dim) != dim || nq < 1) return "";
+  return rr::scan_kernel_name(dim, nq > rr::kQueriesPerBlock ? rr::kQueriesPerBlock : nq, false);
 }
 
 int rr_merge_topk(const float* Din, const int64_t* Iin, int nq, int m, int k, int descending, float* Dout,

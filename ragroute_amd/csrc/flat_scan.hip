@@ -595,6 +595,14 @@ hipError_t launch_flat_scan(const ScanArgs& a, int dtype, int D, bool dense, int
   return f16 ? launch_scan_d<_Float16>(a, D, dense, grid, st) : launch_scan_d<__bf16>(a, D, dense, grid, st);
 }
 
+// the kernel launch_flat_scan dispatches a filter launch of (D, nq queries in the block) to
+const char* scan_kernel_name(int D, int nq, bool l2) {
+  read_variant_env();
+  if (half_resident_dim(D) && nq < g_wide_min_queries && !l2) return "flat_scan16h_kernel";
+  if (D > kMaxResidentDim) return scan_wide_kernel_name(D, nq);
+  return "flat_scan16_kernel";
+}
+
 int scan_padded_dim(int d) {
   static const int dims[] = {128, 256, 384, 512, 640, 768, 896, 1024, 1280, 1536};  // query-resident instantiations
   for (int v : dims)

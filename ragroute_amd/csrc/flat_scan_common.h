@@ -361,6 +361,7 @@ constexpr size_t kNtThresholdBytes = 256ull << 20;
 #define RR_WIDE_QFRAG 1   // the pd / wide8 kernels' query loads read prep_kernel's fragment-order copy (one contiguous KiB per
 #endif                    // instruction) instead of 16 rows x 64 B of the row-major block; 0 = row-major (A/B builds)
 hipError_t launch_scan_wide(const ScanArgs& a, int dtype, int D, bool dense, int grid, hipStream_t st);
+const char* scan_wide_kernel_name(int D, int nq);
 
 // flat_scan_dev.hip (only in builds with -DRR_DEV_VARIANTS): the development kernels behind RR_SCAN_VARIANT / RR_GENERIC_TALL
 bool dev_scan_handles(const ScanArgs& a, int D, int variant, int tall);

@@ -929,6 +929,12 @@ static int wide_waves_for(int D, int nq) {
   return (nblk == 9 || nblk == 11 || nblk == 12) ? 4 : 8;
 }
 
+// name of the filter-launch kernel launch_scan_wide_t picks (reported by rr_flat_scan_kernel_name)
+const char* scan_wide_kernel_name(int D, int nq) {
+  if (wide_pd() == 0) return "flat_scan_wide_kernel";
+  return wide_waves_for(D, nq) == 8 ? "flat_scan_wide8_kernel" : "flat_scan_wide_pd_kernel";
+}
+
 template <typename T>
 static hipError_t launch_scan_wide_t(const ScanArgs& a, int D, bool dense, int grid, hipStream_t st) {
   if (D % 128 != 0) return hipErrorInvalidValue;

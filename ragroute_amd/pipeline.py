@@ -28,6 +28,20 @@ class RetrievalPipeline:
         self.group = group
         self.slots = slots
         self._packed = {}
+        self.stage_events = None   # measurement aid (bench.py): [(exchange start, exchange end = merge start, merge end)] per search
+
+    def time_stages(self, on=True):
+        """Bracket the exchange and the merge of every following search with events on the current stream (bench.py's
+        `exchange_ms` / `merge_ms`); stage_ms() reads them back.  Off by default: three event records per search."""
+        self.stage_events = [] if on else None
+
+    def stage_ms(self):
+        """(mean exchange ms, mean merge ms) over the searches since time_stages(); synchronises on the last event."""
+        ev = self.stage_events or []
+        if not ev:
+            return None, None
+        ev[-1][2].synchronize()
+        return (sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev), sum(b.elapsed_time(c) for _, b, c in ev) / len(ev))
 
     def route(self, xq_models):
         """xq_models: f32 [B, n_models, d_max] -> (logits, bool mask [B, C]) on device, or (None, None) for 'all'."""
@@ -66,5 +80,15 @@ class RetrievalPipeline:
             q = xq[sid] if per_shard else xq
             idx.search_prepared(idx.prepare_queries(q), k, id_offset=sid << SHARD_SHIFT, out=(D[slot], I[slot]),
                                 route_mask=None if mask is None else mask[:, sid])
-        out = exchange_packed(buf, self.group)                       # C1: the ONE collective
-        return merge_gathered(out, B, k, self.slots, k, True)        # K4, reading the gathered buffer where it lies
+        if self.stage_events is None:
+            out = exchange_packed(buf, self.group)                       # C1: the ONE collective
+            return merge_gathered(out, B, k, self.slots, k, True)        # K4, reading the gathered buffer where it lies
+        import torch
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        out = exchange_packed(buf, self.group)
+        e1.record()
+        res = merge_gathered(out, B, k, self.slots, k, True)
+        e2.record()
+        self.stage_events.append((e0, e1, e2))
+        return res
