@@ -383,6 +383,23 @@ def faiss_probe(xb, q, qh, Dg, Ig, k, sample, n):
     gaps_ok = np.ones_like(If, dtype=bool)
     gaps_ok[:, 1:] &= (Df[:, :-1] - Df[:, 1:]) > 2e-3
     gaps_ok[:, :-1] &= (Df[:, :-1] - Df[:, 1:]) > 2e-3
+    # the tie rule (include/ragroute_hip.h: equal scores by ascending row id) against FAISS on integer-valued rows, where every
+    # score is exact and ties are plentiful: does FAISS return the same id SET, and the same ORDER inside runs of equal scores?
+    from ragroute_amd.flat_index import FlatIndex
+    rng = np.random.default_rng(11)
+    xt = rng.integers(-1, 2, size=(30_000, xb.shape[1])).astype(np.float32)
+    qt = rng.integers(-1, 2, size=(32, xb.shape[1])).astype(np.float32)
+    it = faiss.IndexFlatIP(xb.shape[1])
+    it.add(xt)
+    Dt, It = it.search(qt, k)
+    ours = FlatIndex(xb.shape[1])
+    ours.add(xt)
+    Do, Io = ours.search(qt, k)
+    ties = {"scores_identical": bool(np.array_equal(Do, Dt)),
+            "ties_set_identical": bool(all(set(a.tolist()) == set(b.tolist()) for a, b in zip(Io, It))),
+            "ties_order_identical": bool(np.array_equal(Io, It)),
+            "queries_with_a_tie_in_the_result": int(sum(len(set(r.tolist())) < len(r) for r in Dt)),
+            "sample": "30000 x d rows and 32 queries with entries in {-1, 0, 1}, exact scores, k as the bench"}
     x = np.ascontiguousarray(q[:64].copy())
     y = x.copy()
     faiss.normalize_L2(x)
@@ -394,7 +411,8 @@ def faiss_probe(xb, q, qh, Dg, Ig, k, sample, n):
                                          "threads": faiss.omp_get_max_threads()},
             "parity_vs_faiss": {"ids_identical_where_gap_gt_2e-3": bool(np.array_equal(Ig[gaps_ok], If[gaps_ok])),
                                 "positions_compared": int(gaps_ok.sum()), "max_abs_score_diff": float(np.abs(Dg - Df).max()),
-                                "score_tolerance": 1e-3, "normalize_L2_max_abs_diff": float(np.abs(x - y).max())}}
+                                "score_tolerance": 1e-3, "normalize_L2_max_abs_diff": float(np.abs(x - y).max()),
+                                "ties": ties}}
 
 
 def cpu_extra_rows(O, xb, q, k, sample, n):

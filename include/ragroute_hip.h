@@ -70,7 +70,10 @@ size_t rr_flat_search_workspace_bytes(int k);
 /* Exact brute-force inner-product top-k of nq queries against an HBM-resident corpus.
  * Replaces `index.search(query_embed, k)` — reference ragroute/data_source.py:158, 186, 203
  * (med_rag.py:158, mmlu.py:109): returns, per query, the k best rows best-first; ties are
- * broken by ascending row id; if fewer than k rows exist the tail is (-inf, -1) as FAISS pads.
+ * broken by ascending row id — THIS BUILD'S DEFINITION: which of several equally scored rows FAISS 1.7.4 lists first is
+ * unverified (no faiss in the image; tests/test_faiss_parity_gpu.py and bench.py's faiss probe report
+ * `ties_set_identical` / `ties_order_identical` wherever faiss is importable); if fewer than k rows exist the tail is
+ * (-inf, -1) as FAISS pads.
  *   d_xb     device [n_rows][dim] f16/bf16, dim == rr_padded_dim(d) (zero padded)
  *   d_xq     device [nq][dim] same dtype
  *   d_D      device f32 [nq][k]  scores (inner products, f32 accumulation)

@@ -80,7 +80,9 @@ def set_threads(n):
 # ---- a2: index.search — data_source.py:158, 186, 203 -----------------------------------------
 def flat_search_ip(xb, xq, k):
     """(D f32[nq,k], I i64[nq,k]) of an exact inner-product flat index; ties by ascending id,
-    (-inf, -1) padding when k > ntotal.  Scores are f32 roundings of f64 dot products."""
+    (-inf, -1) padding when k > ntotal.  Scores are f32 roundings of f64 dot products.
+    The order INSIDE a run of equal scores (ascending id) is this build's definition: FAISS 1.7.4's is unverified here
+    (parity unpinned, see the module header); tests/test_faiss_parity_gpu.py reports it where faiss is importable."""
     xb = np.ascontiguousarray(xb, dtype=np.float32)
     xq = np.ascontiguousarray(xq, dtype=np.float32).reshape(-1, xb.shape[1] if xb.ndim == 2 and xb.shape[0] else xq.shape[-1])
     nq, d = xq.shape

@@ -248,3 +248,15 @@ def test_list_rerank_needs_no_gpu():
             "assert rerank_medrag(list('abcdefgh'), [.1,.9,.5,.9,.3,.2,.7,.5], 4) == (['b','d','g','c'], [0.9,0.9,0.7,0.5])\n"
             "assert rerank_wikipedia(list('abcdefgh'), [.1,.9,.5,.9,.3,.2,.7,.5], 4) == (['a','f','e','c'], [0.1,0.2,0.3,0.5])\n") % ROOT
     subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, HIP_VISIBLE_DEVICES="-1"))
+
+
+def test_tie_report_of_the_faiss_probe():
+    """The report the faiss probe prints (tests/test_faiss_parity_gpu.py; skipped without faiss) on a hand-made case: same id
+    set, different order inside a run of equal scores."""
+    from tests.util import tie_report
+    Df = np.array([[5, 4, 4, 4, 1], [3, 3, 2, 1, 0]], np.float32)
+    If = np.array([[9, 7, 2, 5, 1], [4, 6, 0, 1, 2]], np.int64)         # "faiss": first run not in ascending id order
+    I = np.array([[9, 2, 5, 7, 1], [4, 6, 0, 1, 2]], np.int64)          # this build: ascending ids inside ties
+    r = tie_report(I, If, Df)
+    assert r == {"ties_set_identical": True, "ties_order_identical": False, "tie_runs_in_faiss_result": 2,
+                 "faiss_tie_runs_in_ascending_id_order": 1}

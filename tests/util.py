@@ -44,6 +44,27 @@ def assert_topk_close(D, I, Dref, Iref, S=None, tol=1e-3):
     return bad
 
 
+def tie_report(I, If, Df):
+    """How FAISS orders EQUAL scores against this build's rule (ascending row id, include/ragroute_hip.h rr_flat_search): per query, the
+    returned id SET (which rows make it past a tie at the k-th score) and the ORDER inside runs of equal scores."""
+    set_same = all(set(a.tolist()) == set(b.tolist()) for a, b in zip(I, If))
+    order_same = bool(np.array_equal(I, If))
+    runs = asc = 0
+    for q in range(If.shape[0]):
+        j = 0
+        while j < If.shape[1]:
+            e = j
+            while e + 1 < If.shape[1] and Df[q, e + 1] == Df[q, j]:
+                e += 1
+            if e > j:
+                runs += 1
+                asc += int(np.all(np.diff(If[q, j:e + 1]) > 0))
+            j = e + 1
+    return {"ties_set_identical": bool(set_same), "ties_order_identical": order_same, "tie_runs_in_faiss_result": runs,
+            "faiss_tie_runs_in_ascending_id_order": asc}
+
+
+
 # ---- synthetic router cases (shared by tests/golden/make_golden.py and the tests) -----------------
 def synth_router_case(dataset, seed, n_queries=8):
     """Seeded synthetic router: state_dict, centroids, scaler statistics and query embeddings with the
