@@ -89,6 +89,33 @@ int rr_flat_search(const void* d_xb, int dtype, int64_t n_rows, int dim, const v
                    float* d_D, int64_t* d_I, int64_t id_offset, void* d_ws, size_t ws_bytes,
                    const uint8_t* d_route_mask, int64_t mask_stride, void* stream);
 
+/* ONE search over several data sources that receive the same query embeddings (the four MedRAG sources all use MedCPT,
+ * five FeB4RAG sources UAE-Large-V1: reference ragroute/config.py:37-71), instead of one `index.search` per source
+ * (data_source.py:158, 186, 203) followed by the front-end's concatenation and `rerank_medrag` (http_server.py:280-293,
+ * rerank.py:3-9): per query, the k best rows of the UNION of the segments the router selected for it, best-first — which is
+ * what merging the per-source top-k lists yields.  One query preparation, one bootstrap and one chunk schedule serve all
+ * sources; small sources no longer pay a search's fixed cost each.
+ *   d_xb      ONE device matrix [n_rows_total][dim]; segment s = rows [row_begin, row_begin + n_rows) of it.  Segments are
+ *             ascending, do not overlap and begin at multiples of RR_SEGMENT_ALIGN rows; rows between segments (alignment
+ *             gaps) may hold anything finite or not — they are scanned but never returned.
+ *   segs      HOST array of n_segs (<= RR_MAX_SEGMENTS) descriptors
+ *   d_I       result ids: id_offset + (row - row_begin) of the row's segment, or -1.  Ties are broken by (segment order,
+ *             row), i.e. by ascending id when the id_offsets ascend with the segments.
+ *   d_route_mask  optional device u8 [nq][mask_stride]: segment s serves query q iff mask_col < 0 or
+ *             d_route_mask[q * mask_stride + mask_col] != 0 (router.py:276-282); a query routed nowhere gets all padding.
+ *   d_ws      as rr_flat_search (rr_flat_search_workspace_bytes(k)).  Inner product / cosine only. */
+typedef struct rr_segment {
+  int64_t row_begin;
+  int64_t n_rows;
+  int64_t id_offset;
+  int32_t mask_col;
+  int32_t reserved;
+} rr_segment;
+enum { RR_MAX_SEGMENTS = 32, RR_SEGMENT_ALIGN = 256 };
+int rr_flat_search_segments(const void* d_xb, int dtype, int64_t n_rows_total, int dim, const rr_segment* segs, int n_segs,
+                            const void* d_xq, int nq, int k, float* d_D, int64_t* d_I, void* d_ws, size_t ws_bytes,
+                            const uint8_t* d_route_mask, int64_t mask_stride, void* stream);
+
 /* The same search under the squared-L2 metric (the role of faiss.IndexFlatL2: the reference's index files decide the metric,
  * data_source.py:71; its wikipedia merge keeps the LOWEST scores, rerank.py:30, i.e. treats scores as distances).  Returns
  * the k nearest rows, nearest first, d_D = |q - x|^2, ties by ascending id, padding (+inf, -1).

@@ -10,12 +10,14 @@ from ._build import LIB_PATH
 RR_DTYPE_F16, RR_DTYPE_BF16 = 0, 1
 RR_MAX_K = 1024
 RR_QUERY_BLOCK = 256
+RR_MAX_SEGMENTS = 32
+RR_SEGMENT_ALIGN = 256
 
 EXPORTS = ("rr_version", "rr_last_error", "rr_device_cus", "rr_padded_dim", "rr_l2_normalize_f32", "rr_rows_to_half",
            "rr_flat_search_workspace_bytes", "rr_flat_search", "rr_merge_topk", "rr_router_mlp", "rr_profile_begin",
            "rr_profile_end", "rr_centroid", "rr_flat_search_l2", "rr_half_sqnorms", "rr_screen_dim", "rr_screen_build",
            "rr_flat_search_screened_workspace_bytes", "rr_flat_search_screened", "rr_router_workspace_bytes", "rr_router_mlp_ws",
-           "rr_build_flags", "rr_merge_topk_gathered", "rr_flat_scan_kernel_name")
+           "rr_build_flags", "rr_merge_topk_gathered", "rr_flat_scan_kernel_name", "rr_flat_search_segments")
 
 
 class RouterWeightsStruct(ctypes.Structure):
@@ -27,6 +29,12 @@ class RouterWeightsStruct(ctypes.Structure):
         ("ln2_g", ctypes.c_void_p), ("ln2_b", ctypes.c_void_p), ("w3", ctypes.c_void_p),
         ("b3", ctypes.c_float), ("prob_threshold", ctypes.c_float), ("ln_eps", ctypes.c_float), ("reserved2", ctypes.c_float),
     ]
+
+
+class SegmentStruct(ctypes.Structure):
+    """struct rr_segment"""
+    _fields_ = [("row_begin", ctypes.c_int64), ("n_rows", ctypes.c_int64), ("id_offset", ctypes.c_int64),
+                ("mask_col", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class RagrouteHipError(RuntimeError):
@@ -56,6 +64,7 @@ def lib():
         L.rr_flat_search_workspace_bytes.restype = sz
         L.rr_flat_search.argtypes = [vp, i32, i64, i32, vp, i32, i32, vp, vp, i64, vp, sz, vp, i64, vp]
         L.rr_merge_topk.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
+        L.rr_flat_search_segments.argtypes = [vp, i32, i64, i32, ctypes.POINTER(SegmentStruct), i32, vp, i32, i32, vp, vp, vp, sz, vp, i64, vp]
         L.rr_merge_topk_gathered.argtypes = [vp, i32, sz, sz, i32, i32, i32, i32, i32, vp, vp, vp]
         L.rr_build_flags.restype = ctypes.c_char_p
         L.rr_flat_scan_kernel_name.argtypes = [i32, i32]

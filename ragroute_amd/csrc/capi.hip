@@ -92,6 +92,8 @@ double chunk_schedule(double ratio, int k) {
 }
 
 struct Workspace {
+  uint32_t *seg_tile_end, *seg_row_limit, *seg_row_begin, *seg_sel;   // segmented search: device tables written by prep_kernel
+  int64_t* seg_id_offset;
   float* thr;
   uint32_t* list_cnt;
   uint64_t* list;
@@ -109,7 +111,12 @@ Workspace carve(char* base, int k, int grid) {
   Workspace w;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return base ? base + o : (char*)nullptr; };
-  w.thr = (float*)take(kQueriesPerBlock * sizeof(float));
+  w.thr = (float*)take((size_t)kMaxSegments * kQueriesPerBlock * sizeof(float));   // [segment][query] (plain search: row 0)
+  w.seg_tile_end = (uint32_t*)take(kMaxSegments * sizeof(uint32_t));
+  w.seg_row_limit = (uint32_t*)take(kMaxSegments * sizeof(uint32_t));
+  w.seg_row_begin = (uint32_t*)take(kMaxSegments * sizeof(uint32_t));
+  w.seg_id_offset = (int64_t*)take(kMaxSegments * sizeof(int64_t));
+  w.seg_sel = (uint32_t*)take(kQueriesPerBlock * sizeof(uint32_t));
   w.list_cnt = (uint32_t*)take(kQueriesPerBlock * sizeof(uint32_t));
   w.list = (uint64_t*)take((size_t)kQueriesPerBlock * kMaxK * sizeof(uint64_t));
   w.cand_cnt = (uint32_t*)take((size_t)kQueriesPerBlock * grid * 4 * sizeof(uint32_t));
@@ -177,9 +184,11 @@ size_t rr_flat_search_workspace_bytes(int k) {
   return carve(nullptr, k, grid).total;
 }
 
+// segs != nullptr: segmented search — xb is ONE matrix of n_rows rows holding several sources (segs->row_begin / row_limit),
+// scanned as one corpus; route_mask then is [nq][mask_stride] with one column per segment (segs->mask_col), id_offset unused.
 static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, const void* xq, int nq, int k, float* D,
                             int64_t* I, int64_t id_offset, void* ws, size_t ws_bytes, const uint8_t* route_mask,
-                            int64_t mask_stride, const float* half_sqnorm, void* stream) {
+                            int64_t mask_stride, const float* half_sqnorm, void* stream, const rr::SegHost* segs = nullptr) {
   using namespace rr;
   hipStream_t st = (hipStream_t)stream;
   if (k < 1 || k > kMaxK) return fail(RR_ERR_INVALID, "rr_flat_search: k must be in [1, 1024]%s");
@@ -213,17 +222,21 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
     s.thr = w.thr; s.list = w.list; s.list_cnt = w.list_cnt; s.cand = w.cand; s.cand_cnt = w.cand_cnt;
     s.dense = w.dense; s.dense_ld = kSampleRows; s.n_rows = (uint32_t)n_rows; s.nq = (uint32_t)nqb;
     s.nbuf = (uint32_t)grid * (uint32_t)(dtype == kDtypeI8 ? 4 : scan_bufs_per_wg(dim, half_sqnorm != nullptr)); s.list_ld = kMaxK; s.cap = cap; s.k = k;
+    if (segs) s.seg = SegTables{w.seg_tile_end, w.seg_row_limit, w.seg_row_begin, w.seg_id_offset, w.seg_sel, segs->n};
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     a.xb = xb; a.xq = xq_b; a.thr = w.thr; a.cand = w.cand; a.cand_cnt = w.cand_cnt; a.scratch = w.scratch;
     a.dense = w.dense; a.n_rows = (uint32_t)n_rows; a.nq = (uint32_t)nqb; a.dense_ld = kSampleRows; a.cap = cap; a.k = k;
     a.half_sqnorm = half_sqnorm;
+    if (segs) { a.seg_tile_end = w.seg_tile_end; a.seg_row_limit = w.seg_row_limit; a.n_segs = segs->n; }
     // (per query block: launch_flat_scan picks the kernel from the block's own query count, e.g. the 44-query tail of a 300-query call)
     const int bpw = dtype == kDtypeI8 ? 4 : scan_query_blocks_per_wave(dim, nqb, half_sqnorm != nullptr);
     a.xqs = bpw ? w.xqs : nullptr;
 
     bool finalized = false;
-    RR_CHECK(launch_prep(s, xq_b, w.xqs, dim, bpw, st), "rr_flat_search/prep");
+    // (segmented: the per-query route mask rows of this query block; folded into the thresholds, not into the finalize)
+    const uint8_t* mask_b = route_mask ? route_mask + (size_t)qb * mask_stride : nullptr;
+    RR_CHECK(launch_prep(s, xq_b, w.xqs, dim, bpw, st, segs, segs ? mask_b : nullptr, mask_stride), "rr_flat_search/prep");
     if (n_rows > 0 && n_rows <= kDenseMaxRows) {
       // tiny corpus: all scores, one exact selection
       a.tile_first = 0; a.tile_stride = 1; a.n_tiles = total_tiles;
@@ -241,7 +254,7 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
       // survivors per query.  The number of chunks balances the fixed cost of a scan launch + compaction against the
       // insertion work of a long chunk (chunk_schedule).
       const double growth = chunk_schedule((double)total_tiles / n_sample_tiles, k);
-      FinalizeArgs fin{D_b, I_b, id_offset, route_mask ? route_mask + (size_t)qb * mask_stride : nullptr, mask_stride};
+      FinalizeArgs fin{D_b, I_b, id_offset, segs ? nullptr : mask_b, mask_stride};
       uint64_t begin = 0;
       double endf = (double)n_sample_tiles * growth;  // in tiles
       while (begin < total_tiles) {
@@ -260,7 +273,7 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
       }
     }
     if (!finalized)
-      RR_CHECK(launch_finalize(s, D_b, I_b, id_offset, route_mask ? route_mask + (size_t)qb * mask_stride : nullptr, mask_stride,
+      RR_CHECK(launch_finalize(s, D_b, I_b, id_offset, segs ? nullptr : mask_b, mask_stride,
                                half_sqnorm ? (const void*)xq_b : nullptr, dtype, dim, st),
                "rr_flat_search/finalize");
   }
@@ -283,6 +296,44 @@ int rr_flat_search_l2(const void* xb, const float* half_sqnorm, int dtype, int64
   static const float kEmpty = 0.f;
   return flat_search_impl(xb, dtype, n_rows, dim, xq, nq, k, D, I, id_offset, ws, ws_bytes, route_mask, mask_stride,
                           half_sqnorm ? half_sqnorm : &kEmpty, stream);
+}
+
+int rr_flat_search_segments(const void* xb, int dtype, int64_t n_rows_total, int dim, const rr_segment* segs, int n_segs,
+                            const void* xq, int nq, int k, float* D, int64_t* I, void* ws, size_t ws_bytes,
+                            const uint8_t* route_mask, int64_t mask_stride, void* stream) {
+  if (dtype != RR_DTYPE_F16 && dtype != RR_DTYPE_BF16) return fail(RR_ERR_INVALID, "rr_flat_search_segments: bad dtype%s");
+  if (n_segs < 1 || n_segs > RR_MAX_SEGMENTS || !segs) return fail(RR_ERR_INVALID, "rr_flat_search_segments: need 1 .. 32 segments%s");
+  if (n_rows_total < 0 || n_rows_total > 0xFFFFFFE0ll) return fail(RR_ERR_INVALID, "rr_flat_search_segments: bad total row count%s");
+  rr::SegHost h;
+  memset(&h, 0, sizeof(h));
+  h.n = (uint32_t)n_segs;
+  int64_t prev_end = 0, valid_rows = 0;
+  int max_col = -1;
+  for (int s = 0; s < n_segs; ++s) {
+    const rr_segment& g = segs[s];
+    if (g.n_rows < 0 || g.row_begin < prev_end || g.row_begin % RR_SEGMENT_ALIGN != 0 || g.row_begin + g.n_rows > n_rows_total)
+      return fail(RR_ERR_INVALID, "rr_flat_search_segments: segments must be ascending, non-overlapping, inside the matrix, and begin at "
+                                  "multiples of 256 rows%s");
+    if (g.mask_col < -1) return fail(RR_ERR_INVALID, "rr_flat_search_segments: mask_col must be >= -1%s");
+    prev_end = g.row_begin + g.n_rows;
+    valid_rows += g.n_rows;
+    if (g.mask_col > max_col) max_col = g.mask_col;
+    h.row_begin[s] = (uint32_t)g.row_begin;
+    h.row_limit[s] = (uint32_t)prev_end;
+    h.mask_col[s] = route_mask ? g.mask_col : -1;
+    h.id_offset[s] = g.id_offset;
+  }
+  if (route_mask && max_col >= 0 && mask_stride <= max_col)
+    return fail(RR_ERR_INVALID, "rr_flat_search_segments: mask_stride must exceed every mask_col%s");
+  // segment s owns the tiles up to the next segment's first row (its alignment gap included); the last one runs to the end of
+  // the rows that are scanned at all: nothing behind the last valid row is read
+  const int64_t scanned = prev_end;
+  for (int s = 0; s < n_segs; ++s) {
+    const int64_t next = s + 1 < n_segs ? segs[s + 1].row_begin : scanned;
+    h.tile_end[s] = (uint32_t)((next + rr::kTileRows - 1) / rr::kTileRows);
+  }
+  (void)valid_rows;
+  return flat_search_impl(xb, dtype, scanned, dim, xq, nq, k, D, I, 0, ws, ws_bytes, route_mask, mask_stride, nullptr, stream, &h);
 }
 
 // ---- int8 screening copy ---------------------------------------------------------------------------------

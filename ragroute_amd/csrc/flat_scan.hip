@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   }
 
   LaneState4 st;
+  lane_state_segments_init(a, st);
   const uint32_t nbuf = gridDim.x * 4;
 #pragma unroll
   for (int qb = 0; qb < 4; ++qb) {
@@ -309,6 +310,8 @@ __global__ __launch_bounds__(256, 1) void flat_scan16h_kernel(const ScanArgs a) 
   }
   float thr[2];
   uint32_t cnt[2], off[2];
+  int seg = -1;                                                        // segmented search (see LaneState4)
+  uint32_t seg_end_tile = a.seg_tile_end ? 0u : 0xFFFFFFFFu, row_limit = a.n_rows;
   const uint32_t nbuf = gridDim.x * 4;
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
@@ -411,6 +414,11 @@ __global__ __launch_bounds__(256, 1) void flat_scan16h_kernel(const ScanArgs a) 
         for (int qb = 0; qb < 2; ++qb)
           *(f32x4*)(a.dense + (size_t)(wave * 32 + qb * 16 + col) * a.dense_ld + j * kTileRows + (u & 1) * 16 + 4 * g) = acc[qb];
       } else {
+        if (a.tile_first + j * a.tile_stride >= seg_end_tile) {   // segmented search: the unit's tile has left the wave's segment
+          seg = segment_advance(a, seg, a.tile_first + j * a.tile_stride, seg_end_tile, row_limit);
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) thr[qb] = asm_load_f32(a.thr + (size_t)seg * kQueriesPerBlock + wave * 32 + qb * 16 + col);
+        }
         const float m0 = max4v(acc[0]), m1 = max4v(acc[1]);
         if (__builtin_amdgcn_ballot_w64(m0 > thr[0] || m1 > thr[1])) {
 #pragma unroll
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan16h_kernel(const ScanArgs a) 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const uint32_t id = row0 + i;
-              if (acc[qb][i] > thr[qb] && id < a.n_rows) {
+              if (acc[qb][i] > thr[qb] && id < row_limit) {
                 a.cand[(size_t)off[qb] + cnt[qb]] = make_key(acc[qb][i], id);
                 ++cnt[qb];
               }

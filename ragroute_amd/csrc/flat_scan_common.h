@@ -254,7 +254,40 @@ __device__ __forceinline__ f32x4 lds_load_f32x4(uint32_t byte_addr) {
 struct LaneState4 {
   float thr[4];
   uint32_t cnt[4], off[4];
+  // segmented search (wave-uniform): the segment the wave's current tile lies in, its first tile past the end, and the first row
+  // past its valid rows.  Plain search: seg_end_tile = ~0 (never reached), row_limit = n_rows.
+  uint32_t seg_end_tile, row_limit;
+  int seg;
 };
+
+// Loads of the rare paths, with their own wait and invisible to hipcc's waitcnt pass: a VMEM load it can see inside a loop that
+// keeps LDS-DMA / prefetched registers in flight makes it put s_waitcnt vmcnt(0) into the hot path (pitfall i).
+// The wait drains the wave's DMA ring too, which is always safe (the counted waits that follow are then met at once).
+__device__ __forceinline__ uint32_t asm_load_u32(const void* p) {
+  uint32_t v;
+  asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ float asm_load_f32(const void* p) { return __uint_as_float(asm_load_u32(p)); }
+
+__device__ __forceinline__ void lane_state_segments_init(const ScanArgs& a, LaneState4& st) {
+  st.seg = -1;
+  st.seg_end_tile = a.seg_tile_end ? 0u : 0xFFFFFFFFu;   // segmented: the first tile enters segment_advance
+  st.row_limit = a.n_rows;
+}
+// The wave's tile has left its segment (a workgroup's tiles only move forward, so this happens at most n_segs times per
+// launch): find the segment of `tile`, its end and its valid-row limit.  Returns the segment; the caller reloads its thresholds
+// from a.thr[seg][query] (+inf for queries not routed there: nothing of them passes the filter).
+__device__ __forceinline__ int segment_advance(const ScanArgs& a, int seg, uint32_t tile, uint32_t& seg_end_tile, uint32_t& row_limit) {
+  uint32_t end;
+  do {
+    ++seg;
+    end = (uint32_t)__builtin_amdgcn_readfirstlane((int)asm_load_u32(a.seg_tile_end + seg));
+  } while (tile >= end && seg + 1 < (int)a.n_segs);
+  seg_end_tile = end;
+  row_limit = (uint32_t)__builtin_amdgcn_readfirstlane((int)asm_load_u32(a.seg_row_limit + seg));
+  return seg;
+}
 
 __device__ __forceinline__ float max4v(const f32x4& v) { return max4(v[0], v[1], v[2], v[3]); }
 
@@ -273,6 +306,12 @@ __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& s
       *(f32x4*)(d + 16) = acc[1][qb];
     }
     return;
+  }
+  if (tile >= st.seg_end_tile) {   // segmented search only (plain: seg_end_tile = ~0); wave-uniform, a handful of times per launch
+    st.seg = segment_advance(a, st.seg, tile, st.seg_end_tile, st.row_limit);
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb)
+      st.thr[qb] = asm_load_f32(a.thr + (size_t)st.seg * kQueriesPerBlock + (DEAL ? (qb * 4 + wave) * 16 + col : wave * QPW + qb * 16 + col));
   }
 #ifndef RR_EPILOGUE_MASKS
 #define RR_EPILOGUE_MASKS 0   // 1: the insertion path branches on wave masks made by the filter instead of re-deriving them per group (measured: headline -0.4 %, config 2 +0.8 %, i.e. noise; off)
@@ -312,7 +351,7 @@ __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& s
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const uint32_t id = row0 + rb * 16 + i;
-          if (acc[rb][qb][i] > st.thr[qb] && id < a.n_rows) {
+          if (acc[rb][qb][i] > st.thr[qb] && id < st.row_limit) {
             a.cand[(size_t)st.off[qb] + st.cnt[qb]] = make_key(acc[rb][qb][i], id);
             ++st.cnt[qb];
           }

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(512, 2) void flat_scan16x8_kernel(const ScanArgs a)
   }
 
   LaneState4 st;
+  lane_state_segments_init(a, st);
   const uint32_t nbuf = gridDim.x * 4;
 #pragma unroll
   for (int qb = 0; qb < 4; ++qb) {

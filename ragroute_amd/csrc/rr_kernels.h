@@ -6,11 +6,29 @@
 
 namespace rr {
 
+constexpr int kMaxSegments = 32;   // RR_MAX_SEGMENTS
+
+// Segmented search (rr_flat_search_segments): one matrix holds several data sources that receive the same query block.  The
+// scan walks the whole matrix as one corpus of "virtual" rows; these device tables (written by prep_kernel) say which rows
+// belong to which source.  Segment s owns tiles [tile_end[s-1], tile_end[s]) (its alignment gap included) and its VALID rows
+// are [row_begin[s], row_limit[s]).
+struct SegTables {
+  const uint32_t* tile_end;    // [n] first tile past segment s
+  const uint32_t* row_limit;   // [n] first row past the valid rows of segment s
+  const uint32_t* row_begin;   // [n]
+  const int64_t* id_offset;    // [n] result id = id_offset[s] + (row - row_begin[s])
+  const uint32_t* sel;         // [256] per query: bit s set = the router selected segment s for it
+  uint32_t n;                  // 0 = plain search (one corpus, no tables)
+};
+
 struct ScanArgs {
   const void* xb;       // [n_rows][D] f16/bf16 corpus (D = padded dim)
   const void* xq;       // [nq][D] queries, same dtype
   const void* xqs;      // the same queries in MFMA-fragment order (prep kernel): [wave 4][block 4 or 2][k slice D/32][lane 64][8 elements] (wide rows: 16 blocks)
-  const float* thr;     // [256] strict thresholds (filter mode)
+  const float* thr;     // [256] strict thresholds (filter mode); segmented: [n_segs][256], +inf where the query is not routed to the segment
+  const uint32_t* seg_tile_end;   // segmented search: SegTables::tile_end / row_limit (nullptr: plain search)
+  const uint32_t* seg_row_limit;
+  uint32_t n_segs;
   uint64_t* cand;       // [256][grid*2][cap] candidate keys (filter mode)
   uint32_t* cand_cnt;   // [256][grid*2]
   uint64_t* scratch;    // [grid*4][cap] per-wave compaction scratch
@@ -33,7 +51,8 @@ int scan_query_blocks_per_wave(int D, int nq, bool l2);  // 4 / 2: the kernel re
 
 // select.hip
 struct SelectArgs {
-  float* thr;           // [256]
+  float* thr;           // [256]; segmented: [n_segs][256]
+  SegTables seg;        // seg.n == 0: plain search
   uint64_t* list;       // [256][list_ld] running top-k keys, sorted descending
   uint32_t* list_cnt;   // [256]
   const uint64_t* cand; const uint32_t* cand_cnt;  // as ScanArgs
@@ -44,7 +63,15 @@ struct SelectArgs {
   int cap, k;
 };
 // init_state + copy of the query block into fragment order (xqs; nullptr or blocks_per_wave == 0: init only)
-hipError_t launch_prep(const SelectArgs& a, const void* xq, void* xqs, int dim, int blocks_per_wave, hipStream_t st);
+// segs != nullptr: also writes the device segment tables (a.seg points at them) and the per-query selection bits from the route mask
+struct SegHost {                      // by value in prep_kernel's kernarg
+  uint32_t n;
+  uint32_t tile_end[kMaxSegments], row_limit[kMaxSegments], row_begin[kMaxSegments];
+  int32_t mask_col[kMaxSegments];
+  int64_t id_offset[kMaxSegments];
+};
+hipError_t launch_prep(const SelectArgs& a, const void* xq, void* xqs, int dim, int blocks_per_wave, hipStream_t st,
+                       const SegHost* segs = nullptr, const uint8_t* route_mask = nullptr, int64_t mask_stride = 0);
 hipError_t launch_dense_select(const SelectArgs& a, bool bootstrap, hipStream_t st);
 // fin != nullptr: this is the last compaction of an inner-product search, emit (D, I) directly (no finalize launch)
 struct FinalizeArgs { float* D; int64_t* I; int64_t id_offset; const uint8_t* mask; int64_t mask_stride; };

@@ -6,6 +6,8 @@
 //  * merge_topk   : cross-source (score, id) merge — reference ragroute/rerank.py:3-9, 28-34
 // All of them order candidates by (score descending, id ascending); one workgroup per query,
 // bitonic sort of 64-bit order keys in LDS.
+#include <string.h>
+
 #include "rr_common.h"
 #include "rr_kernels.h"
 #include "rr_sort.h"
@@ -20,15 +22,57 @@ __device__ __forceinline__ float next_below(float x) {
   return __uint_as_float((b & 0x80000000u) ? b + 1 : b - 1);
 }
 
+// ---- segmented search helpers ---------------------------------------------------------------------------------------------
+// segment of a virtual row (<= 32 segments: a linear walk over the tile ends)
+__device__ __forceinline__ int seg_of_row(const SegTables& t, uint32_t row) {
+  const uint32_t tile = row / kTileRows;
+  int s = 0;
+  while (s + 1 < (int)t.n && tile >= t.tile_end[s]) ++s;
+  return s;
+}
+// is `row` a row some source really holds (not alignment gap), in a segment the query is routed to?
+__device__ __forceinline__ bool seg_row_counts(const SegTables& t, uint32_t row, uint32_t sel_bits) {
+  const int s = seg_of_row(t, row);
+  return row >= t.row_begin[s] && row < t.row_limit[s] && ((sel_bits >> s) & 1u);
+}
+__device__ __forceinline__ int64_t seg_result_id(const SegTables& t, uint32_t row) {
+  const int s = seg_of_row(t, row);
+  return t.id_offset[s] + (int64_t)(row - t.row_begin[s]);
+}
+// publish a query's threshold: plain search one value; segmented one per segment, +inf where the query is not routed
+__device__ __forceinline__ void publish_thr(const SelectArgs& a, uint32_t q, float v) {
+  if (a.seg.n == 0) { a.thr[q] = v; return; }
+  const uint32_t bits = a.seg.sel[q];
+  for (uint32_t s = 0; s < a.seg.n; ++s) a.thr[s * kQueriesPerBlock + q] = ((bits >> s) & 1u) ? v : __builtin_inff();
+}
+
 // One launch in front of every search: per-query state, and the query block copied into the order in which the query-resident scan
 // kernels' waves load their MFMA B fragments: [wave][16-query block (4 per wave at d <= 768, 2 at 768 < d <= 1536)][32-wide k slice][lane][8 elements], so that each
 // of the 96 loads of a wave (d = 768) is one contiguous KiB instead of 16 rows x 64 B.  (The row-major loads cost ~16 us of
 // every scan launch: 5 launches per search.)  Slots past nq repeat the last query, as the kernel's clamped loads did.
-__global__ __launch_bounds__(256) void prep_kernel(SelectArgs a, const uint4* __restrict__ xq, uint4* __restrict__ xqs, int dim, int n_blocks) {
+// Segmented search (segs.n > 0): block 0 also writes the device segment tables and, per query, the selection bits (bit s = the
+// route mask selects segment s for this query, or the segment has no mask column) and the initial thresholds per segment.
+__global__ __launch_bounds__(256) void prep_kernel(SelectArgs a, const uint4* __restrict__ xq, uint4* __restrict__ xqs, int dim, int n_blocks,
+                                                   SegHost segs, const uint8_t* __restrict__ route_mask, int64_t mask_stride) {
   if (blockIdx.x == 0) {
     const uint32_t q = threadIdx.x;
     a.list_cnt[q] = 0;
-    a.thr[q] = q < a.nq ? -__builtin_inff() : __builtin_inff();
+    if (segs.n == 0) {
+      a.thr[q] = q < a.nq ? -__builtin_inff() : __builtin_inff();
+    } else {
+      if (q < segs.n) {
+        const_cast<uint32_t*>(a.seg.tile_end)[q] = segs.tile_end[q];
+        const_cast<uint32_t*>(a.seg.row_limit)[q] = segs.row_limit[q];
+        const_cast<uint32_t*>(a.seg.row_begin)[q] = segs.row_begin[q];
+        const_cast<int64_t*>(a.seg.id_offset)[q] = segs.id_offset[q];
+      }
+      uint32_t bits = 0;
+      if (q < a.nq)
+        for (uint32_t s = 0; s < segs.n; ++s)
+          if (segs.mask_col[s] < 0 || !route_mask || route_mask[(size_t)q * mask_stride + segs.mask_col[s]]) bits |= 1u << s;
+      const_cast<uint32_t*>(a.seg.sel)[q] = bits;
+      for (uint32_t s = 0; s < segs.n; ++s) a.thr[s * kQueriesPerBlock + q] = ((bits >> s) & 1u) ? -__builtin_inff() : __builtin_inff();
+    }
   }
   if (!xqs) return;
   const int ks2 = dim >> 5;                       // 32-wide k slices
@@ -100,6 +144,7 @@ __global__ __launch_bounds__(1024) void dense_select_kernel(SelectArgs a) {
   const int n = (int)a.dense_cols;
   constexpr int PER = kSelectCap / 1024;
   uint32_t ordk[PER], ids[PER];
+  const uint32_t sel_bits = a.seg.n ? a.seg.sel[q] : 0u;
 #pragma unroll
   for (int e = 0; e < PER; ++e) {
     const int c = threadIdx.x + e * 1024;
@@ -107,7 +152,8 @@ __global__ __launch_bounds__(1024) void dense_select_kernel(SelectArgs a) {
     if (c < n) {
       row = (a.tile_first + (uint32_t)(c >> 5) * a.tile_stride) * kTileRows + (c & 31);
       const float s = a.dense[(size_t)q * a.dense_ld + c];
-      if (row < a.n_rows) o = ord_f32(s);  // NaN -> 0 = absent
+      const bool counts = a.seg.n ? seg_row_counts(a.seg, row, sel_bits) : row < a.n_rows;
+      if (counts) o = ord_f32(s);  // NaN -> 0 = absent
     }
     ordk[e] = o;
     ids[e] = row;
@@ -115,7 +161,7 @@ __global__ __launch_bounds__(1024) void dense_select_kernel(SelectArgs a) {
   if (threadIdx.x == 0) fill_s = 0;
   const uint32_t kth = radix_select_kth<PER>(ordk, (uint32_t)a.k, hist, sel);  // ends with a barrier
   if (BOOTSTRAP) {
-    if (threadIdx.x == 0 && kth != 0 && a.k <= n) a.thr[q] = next_below(unord_f32(kth));
+    if (threadIdx.x == 0 && kth != 0 && a.k <= n) publish_thr(a, q, next_below(unord_f32(kth)));
     return;
   }
   // kth == 0: fewer than k valid rows -> keep every valid one
@@ -222,7 +268,7 @@ __global__ __launch_bounds__(1024) void compact_kernel(SelectArgs a, FinalizeArg
       int64_t id = -1;
       if (i < cnt) {
         sc = key_score(sorted[i]);
-        id = (int64_t)key_id(sorted[i]) + fin.id_offset;
+        id = a.seg.n ? seg_result_id(a.seg, key_id(sorted[i])) : (int64_t)key_id(sorted[i]) + fin.id_offset;
       }
       fin.D[(size_t)q * k + i] = sc;
       fin.I[(size_t)q * k + i] = id;
@@ -233,7 +279,7 @@ __global__ __launch_bounds__(1024) void compact_kernel(SelectArgs a, FinalizeArg
   if (tid == 0) {
     a.list_cnt[q] = fill;
     // strict threshold: every later row has a larger id than the k listed rows, so a tie loses
-    if (fill == k) a.thr[q] = key_score(sorted[k - 1]);
+    if (fill == k) publish_thr(a, q, key_score(sorted[k - 1]));
   }
 }
 
@@ -265,7 +311,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(SelectArgs a, float* D, i
       const uint64_t key = a.list[(size_t)q * a.list_ld + i];
       s = key_score(key);
       if (L2) s = qn - 2.f * s;
-      id = (int64_t)key_id(key) + id_offset;
+      id = a.seg.n ? seg_result_id(a.seg, key_id(key)) : (int64_t)key_id(key) + id_offset;
     }
     D[(size_t)q * a.k + i] = s;
     I[(size_t)q * a.k + i] = id;
@@ -336,12 +382,16 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const MergeSrc src, in
   }
 }
 
-hipError_t launch_prep(const SelectArgs& a, const void* xq, void* xqs, int dim, int blocks_per_wave, hipStream_t st) {
+hipError_t launch_prep(const SelectArgs& a, const void* xq, void* xqs, int dim, int blocks_per_wave, hipStream_t st,
+                       const SegHost* segs, const uint8_t* route_mask, int64_t mask_stride) {
   const bool swz = xqs && blocks_per_wave > 0 && dim % 32 == 0;
   // wide rows, at most 16 queries: the few-query kernels read block 0 only (the reference's call shape is one query)
   const int n_blocks = (dim > 2 * kMaxResidentDim && a.nq <= 16) ? 1 : 4 * blocks_per_wave;
   const int blocks = swz ? (n_blocks * (dim / 32) * 64 + 255) / 256 : 1;
-  hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, st, a, (const uint4*)xq, swz ? (uint4*)xqs : nullptr, dim, n_blocks);
+  SegHost none;
+  memset(&none, 0, sizeof(none));
+  hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, st, a, (const uint4*)xq, swz ? (uint4*)xqs : nullptr, dim, n_blocks,
+                     segs ? *segs : none, route_mask, mask_stride);
   return hipGetLastError();
 }
 hipError_t launch_dense_select(const SelectArgs& a, bool bootstrap, hipStream_t st) {

@@ -250,3 +250,115 @@ class FlatIndex:
         with torch.cuda.device(self.device):
             D, I = self.search_prepared(self.prepare_queries(xq), int(k))
             return D.cpu().numpy(), I.cpu().numpy()
+
+
+class SegmentedIndex:
+    """Several data sources that are searched with the SAME query embeddings, resident in ONE HBM matrix and searched in ONE
+    pass (C ABI `rr_flat_search_segments`): MedRAG's four sources all use MedCPT, five FeB4RAG sources UAE-Large-V1
+    (reference ragroute/config.py:37-71).  The reference asks every selected source separately (`index.search`,
+    data_source.py:158, 186, 203) and its front-end concatenates the replies and keeps the k best (http_server.py:280-293,
+    rerank.py:3-9); `search_prepared` returns exactly that merged list — per query, the k best rows of the union of the
+    sources the router selected for it — with one query preparation, one bootstrap and one chunk schedule for all of them.
+
+    Source s occupies rows [begin_s, begin_s + n_s) of the matrix, begin_s a multiple of 256; `source(s)` is a FlatIndex on that
+    slice (no copy), so the per-source call surface (`DataSource.retrieve_docs_*`) keeps working on the same memory.
+    Result ids are id_offsets[s] + local row; ties are broken by (source order, row) = ascending id when the id offsets ascend.
+    Metrics: "ip" / "cosine"."""
+
+    def __init__(self, d, rows_per_source, id_offsets=None, mask_cols=None, metric="ip", dtype="fp16", device=None):
+        if metric not in ("ip", "cosine"):
+            raise ValueError("SegmentedIndex serves the ip / cosine metrics")
+        rows = [int(n) for n in rows_per_source]
+        if not 1 <= len(rows) <= _lib.RR_MAX_SEGMENTS or min(rows) < 0:
+            raise ValueError(f"need 1 .. {_lib.RR_MAX_SEGMENTS} sources with >= 0 rows each")
+        self._proto = FlatIndex(d, metric=metric, dtype=dtype, device=device)   # query conversion, workspace, dims
+        self.d, self.dim, self.metric, self.dtype, self.device = self._proto.d, self._proto.dim, metric, dtype, self._proto.device
+        self.rows = rows
+        self.id_offsets = [int(v) for v in (id_offsets if id_offsets is not None else [s << 40 for s in range(len(rows))])]
+        self.mask_cols = [int(v) for v in (mask_cols if mask_cols is not None else range(len(rows)))]
+        if len(self.id_offsets) != len(rows) or len(self.mask_cols) != len(rows):
+            raise ValueError("one id offset and one mask column per source")
+        A = _lib.RR_SEGMENT_ALIGN
+        self.begins, off = [], 0
+        for n in rows:
+            self.begins.append(off)
+            off += -(-n // A) * A
+        self.n_rows_total = self.begins[-1] + rows[-1]            # nothing behind the last valid row is ever read
+        if self.n_rows_total > 0xFFFFFFE0:
+            raise ValueError("more than 2^32 - 32 rows in one segmented matrix")
+        self._xb = torch.zeros((max(1, self.n_rows_total), self.dim), dtype=_TORCH_DTYPE[dtype], device=self.device)
+        self._segs = (_lib.SegmentStruct * len(rows))(*[_lib.SegmentStruct(b, n, o, c, 0)
+                                                        for b, n, o, c in zip(self.begins, rows, self.id_offsets, self.mask_cols)])
+        self.ntotal = sum(rows)
+
+    def rows_of(self, s):
+        """Device view [n_s, dim] of source s (fill it with rows in the index dtype, zero padded to dim)."""
+        return self._xb[self.begins[s]: self.begins[s] + self.rows[s]]
+
+    def source(self, s):
+        """FlatIndex over source s's slice of the matrix (no copy): the per-source search surface on the same memory."""
+        idx = FlatIndex(self.d, metric=self.metric, dtype=self.dtype, device=self.device)
+        idx.adopt(self.rows_of(s))
+        return idx
+
+    def fill(self, s, x, chunk_rows=1 << 18):
+        """Ingest float32 rows [n_s, d] (numpy or tensor) into source s (normalised for cosine)."""
+        if x.shape[0] != self.rows[s] or x.shape[1] != self.d:
+            raise ValueError(f"source {s} holds [{self.rows[s]}, {self.d}] rows")
+        out = self.rows_of(s)
+        with torch.cuda.device(self.device):
+            for b in range(0, x.shape[0], chunk_rows):
+                part = x[b: b + chunk_rows]
+                if isinstance(part, np.ndarray):
+                    part = torch.from_numpy(np.ascontiguousarray(part, dtype=np.float32))
+                part = part.to(self.device, dtype=torch.float32).contiguous()
+                check(lib().rr_rows_to_half(part.data_ptr(), part.shape[0], self.d, self.d, out[b: b + part.shape[0]].data_ptr(),
+                                            _RR_DTYPE[self.dtype], self.dim, int(self.metric == "cosine"), _stream_ptr()), "rr_rows_to_half")
+
+    @classmethod
+    def from_indexes(cls, indexes, id_offsets=None, mask_cols=None):
+        """Pack existing FlatIndex objects (same d / metric / dtype / device) into one matrix and re-point each of them at its
+        slice, so their own buffers can be released."""
+        first = indexes[0]
+        for i in indexes:
+            if (i.d, i.metric, i.dtype, i.device) != (first.d, first.metric, first.dtype, first.device):
+                raise ValueError("sources of one SegmentedIndex share dimension, metric, dtype and device")
+        seg = cls(first.d, [i.ntotal for i in indexes], id_offsets, mask_cols, first.metric, first.dtype, first.device)
+        for s, i in enumerate(indexes):
+            seg.rows_of(s).copy_(i.xb)
+            i.adopt(seg.rows_of(s))
+        return seg
+
+    def prepare_queries(self, xq):
+        return self._proto.prepare_queries(xq)
+
+    def search_prepared(self, xq_half, k, route_mask=None, out=None):
+        """xq_half [nq, dim] index dtype -> (D f32 [nq,k], I i64 [nq,k]) CUDA tensors: the merged top-k over the selected sources.
+        route_mask: optional bool/uint8 CUDA matrix [nq, C] (the router's mask; source s reads column mask_cols[s])."""
+        if xq_half.dtype != self._xb.dtype or xq_half.dim() != 2 or xq_half.shape[1] != self.dim or not xq_half.is_contiguous():
+            raise ValueError("search_prepared() needs contiguous [nq, dim] queries of the index dtype")
+        nq = xq_half.shape[0]
+        ws = self._proto._workspace(k)
+        if out is None:
+            D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        else:
+            D, I = out
+        mptr, mstride = None, 0
+        if route_mask is not None:
+            if (route_mask.dtype not in (torch.bool, torch.uint8) or route_mask.dim() != 2 or route_mask.shape[0] != nq
+                    or not route_mask.is_cuda or route_mask.stride(1) != 1 or route_mask.shape[1] <= max(self.mask_cols)):
+                raise ValueError("route_mask must be a bool/uint8 CUDA matrix [nq, C] with unit column stride covering every mask column")
+            mptr, mstride = route_mask.data_ptr(), route_mask.stride(0)
+        check(lib().rr_flat_search_segments(self._xb.data_ptr(), _RR_DTYPE[self.dtype], self.n_rows_total, self.dim, self._segs,
+                                            len(self.rows), xq_half.data_ptr(), nq, k, D.data_ptr(), I.data_ptr(), ws.data_ptr(),
+                                            ws.numel(), mptr, mstride, _stream_ptr()), "rr_flat_search_segments")
+        return D, I
+
+    def search(self, xq, k, route_mask=None):
+        """float32 [nq,d] -> (D, I) numpy arrays (merged over the selected sources)."""
+        with torch.cuda.device(self.device):
+            if route_mask is not None and not isinstance(route_mask, torch.Tensor):
+                route_mask = torch.from_numpy(np.ascontiguousarray(route_mask, dtype=np.uint8)).to(self.device)
+            D, I = self.search_prepared(self.prepare_queries(xq), int(k), route_mask)
+            return D.cpu().numpy(), I.cpu().numpy()

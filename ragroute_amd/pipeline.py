@@ -15,11 +15,16 @@ from .sharded import SHARD_SHIFT, alloc_packed, exchange_packed, max_over_ranks,
 
 
 class RetrievalPipeline:
-    def __init__(self, shards, shard_ids, router=None, group=None, slots=None):
+    def __init__(self, shards, shard_ids, router=None, group=None, slots=None, share_queries=None):
         """shards: FlatIndex objects local to this rank (any mix of widths: FeB4RAG's sources are 768 / 1024 / 4096 wide,
         config.py:45-57); shard_ids: their global source ids (columns of the router mask); router: FoldedRouter (or None =
-        routing strategy "all"); slots: candidate slots per rank in the exchange = the largest local shard count over the
-        ranks (default: agreed on by one all_reduce at the first search)."""
+        routing strategy "all"); slots: candidate slots per rank in the exchange = the largest local unit count over the
+        ranks (default: agreed on by one all_reduce at the first search).
+        share_queries: optional list, one hashable key per shard — shards with the same key receive the SAME query
+        embeddings (the key is the encoder: config.py:37-71; MedRAG's four sources all use MedCPT, five FeB4RAG sources
+        UAE-Large-V1).  Local shards that share a key, dimension, metric and dtype are packed into one SegmentedIndex and
+        searched in ONE pass (`rr_flat_search_segments`) whose result is already their merged top-k: one exchange slot per
+        group instead of one per shard.  The shard objects are re-pointed at their slices of the packed matrix."""
         if len(shards) != len(shard_ids):
             raise ValueError("one shard id per shard")
         self.shards = list(shards)
@@ -28,6 +33,29 @@ class RetrievalPipeline:
         self.group = group
         self.slots = slots
         self._packed = {}
+        # units: what one scan call serves and one exchange slot carries: ("shard", FlatIndex, [sid]) or ("segments", SegmentedIndex, [sids])
+        self.units = []
+        if share_queries is None:
+            self.units = [("shard", idx, [sid]) for idx, sid in zip(self.shards, self.shard_ids)]
+        else:
+            if len(share_queries) != len(self.shards):
+                raise ValueError("one share_queries key per shard")
+            from .flat_index import SegmentedIndex
+            groups = {}
+            for idx, sid, key in zip(self.shards, self.shard_ids, share_queries):
+                if getattr(idx, "metric", None) in ("ip", "cosine"):
+                    groups.setdefault((key, idx.d, idx.metric, idx.dtype), []).append((sid, idx))
+                else:
+                    self.units.append(("shard", idx, [sid]))
+            for members in groups.values():
+                members.sort(key=lambda m: m[0])      # ascending source id = ascending id offset: ties by ascending global id
+                if len(members) == 1:
+                    self.units.append(("shard", members[0][1], [members[0][0]]))
+                else:
+                    sids = [m[0] for m in members]
+                    seg = SegmentedIndex.from_indexes([m[1] for m in members], id_offsets=[s << SHARD_SHIFT for s in sids], mask_cols=sids)
+                    self.units.append(("segments", seg, sids))
+            self.units.sort(key=lambda u: u[2][0])
         self.stage_events = None   # measurement aid (bench.py): [(exchange start, exchange end = merge start, merge end)] per search
 
     def time_stages(self, on=True):
@@ -51,9 +79,9 @@ class RetrievalPipeline:
 
     def _buffers(self, B, k, device):
         if self.slots is None:
-            self.slots = max(1, max_over_ranks(len(self.shards), device, self.group))
-        if len(self.shards) > self.slots:
-            raise ValueError(f"{len(self.shards)} local shards but only {self.slots} exchange slots")
+            self.slots = max(1, max_over_ranks(len(self.units), device, self.group))
+        if len(self.units) > self.slots:
+            raise ValueError(f"{len(self.units)} local search units but only {self.slots} exchange slots")
         key = (B, k)
         if key not in self._packed:
             buf, D, I = alloc_packed(B, k, device, self.slots)
@@ -76,10 +104,13 @@ class RetrievalPipeline:
             first = xq
         B = first.shape[0]
         buf, D, I = self._buffers(B, k, first.device)
-        for slot, (idx, sid) in enumerate(zip(self.shards, self.shard_ids)):
-            q = xq[sid] if per_shard else xq
-            idx.search_prepared(idx.prepare_queries(q), k, id_offset=sid << SHARD_SHIFT, out=(D[slot], I[slot]),
-                                route_mask=None if mask is None else mask[:, sid])
+        for slot, (kind, idx, sids) in enumerate(self.units):
+            q = xq[sids[0]] if per_shard else xq          # (a group shares one encoder: any member's embedding)
+            if kind == "segments":
+                idx.search_prepared(idx.prepare_queries(q), k, route_mask=mask, out=(D[slot], I[slot]))
+            else:
+                idx.search_prepared(idx.prepare_queries(q), k, id_offset=sids[0] << SHARD_SHIFT, out=(D[slot], I[slot]),
+                                    route_mask=None if mask is None else mask[:, sids[0]])
         if self.stage_events is None:
             out = exchange_packed(buf, self.group)                       # C1: the ONE collective
             return merge_gathered(out, B, k, self.slots, k, True)        # K4, reading the gathered buffer where it lies
