@@ -15,7 +15,7 @@ from .sharded import SHARD_SHIFT, alloc_packed, exchange_packed, max_over_ranks,
 
 
 class RetrievalPipeline:
-    def __init__(self, shards, shard_ids, router=None, group=None, slots=None, share_queries=None):
+    def __init__(self, shards, shard_ids, router=None, group=None, slots=None, share_queries=None, units=None):
         """shards: FlatIndex objects local to this rank (any mix of widths: FeB4RAG's sources are 768 / 1024 / 4096 wide,
         config.py:45-57); shard_ids: their global source ids (columns of the router mask); router: FoldedRouter (or None =
         routing strategy "all"); slots: candidate slots per rank in the exchange = the largest local unit count over the
@@ -24,7 +24,9 @@ class RetrievalPipeline:
         embeddings (the key is the encoder: config.py:37-71; MedRAG's four sources all use MedCPT, five FeB4RAG sources
         UAE-Large-V1).  Local shards that share a key, dimension, metric and dtype are packed into one SegmentedIndex and
         searched in ONE pass (`rr_flat_search_segments`) whose result is already their merged top-k: one exchange slot per
-        group instead of one per shard.  The shard objects are re-pointed at their slices of the packed matrix."""
+        group instead of one per shard.  The shard objects are re-pointed at their slices of the packed matrix.
+        units: alternatively, the search units themselves — a list of (FlatIndex | SegmentedIndex, [source ids]) built by the
+        caller (a SegmentedIndex filled in place never holds its sources twice)."""
         if len(shards) != len(shard_ids):
             raise ValueError("one shard id per shard")
         self.shards = list(shards)
@@ -35,7 +37,10 @@ class RetrievalPipeline:
         self._packed = {}
         # units: what one scan call serves and one exchange slot carries: ("shard", FlatIndex, [sid]) or ("segments", SegmentedIndex, [sids])
         self.units = []
-        if share_queries is None:
+        if units is not None:
+            from .flat_index import SegmentedIndex
+            self.units = [("segments" if isinstance(obj, SegmentedIndex) else "shard", obj, [int(s) for s in sids]) for obj, sids in units]
+        elif share_queries is None:
             self.units = [("shard", idx, [sid]) for idx, sid in zip(self.shards, self.shard_ids)]
         else:
             if len(share_queries) != len(self.shards):

@@ -1,6 +1,9 @@
 """BASELINE configs 3 and 4 at their real corpus SHAPES on one MI355X (synthetic embeddings, resident in HBM).
 
-    python tools/config34.py medrag|feb4rag [batches]
+    python tools/config34.py medrag|feb4rag [batches] [per-source|segments]
+
+  segments (default): sources that share an encoder (config.py:37-71) live in one SegmentedIndex and are searched in ONE pass
+  (rr_flat_search_segments); per-source: one search per source, as in round 2.
 
   medrag   (config 3: "medrag 4 corpora on 1 GPU + router MLP forward, query batch=256"): pubmed / statpearls / textbooks /
            wikipedia at MedRAG's snippet counts, 768 wide (config.py:28, 45), k = 32, router over 4 sources.
@@ -20,7 +23,7 @@ import numpy as np
 import torch
 
 from ragroute_amd import config as C
-from ragroute_amd.flat_index import FlatIndex
+from ragroute_amd.flat_index import FlatIndex, SegmentedIndex
 from ragroute_amd.pipeline import RetrievalPipeline
 from ragroute_amd.router import CorpusRoutingNN, FoldedRouter
 
@@ -34,10 +37,10 @@ WIDTH = {"e5-large": 1024, "SGPT-5.8B-weightedmean-msmarco-specb-bitfit": 4096, 
          "multilingual-e5-large": 1024, "ember-v1": 1024, "e5-base": 768, "gte-base": 768, "ncbi/MedCPT-Query-Encoder": 768}
 
 
-def make(n, d, dim, seed, dev):
+def make(n, d, dim, seed, dev, out=None):
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
-    xb = torch.zeros((n, dim), dtype=torch.float16, device=dev)
+    xb = torch.zeros((n, dim), dtype=torch.float16, device=dev) if out is None else out
     for s in range(0, n, 1 << 20):
         e = min(n, s + (1 << 20))
         x = torch.randn((e - s, d), generator=g, device=dev)
@@ -48,21 +51,37 @@ def make(n, d, dim, seed, dev):
 def main():
     dataset = sys.argv[1] if len(sys.argv) > 1 else "medrag"
     batches = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    mode = sys.argv[3] if len(sys.argv) > 3 else "segments"
     dev = torch.device("cuda:0")
     sources = C.DATA_SOURCES[dataset]
     model_of = {s: C.EMBEDDING_MODELS_PER_DATA_SOURCE[dataset][s][0] for s in sources}
     models = sorted(set(model_of.values()))
     d_max, k, B = C.EMBEDDING_MAX_LENGTH[dataset], C.K[dataset], 256
-    shards, cents, total_bytes = [], [], 0
+    shards, cents, total_bytes, units = [None] * len(sources), [None] * len(sources), 0, []
+    by_model = {}
     for i, s in enumerate(sources):
-        d = WIDTH[model_of[s]]
-        idx = FlatIndex(d, device=dev)
-        idx.adopt(make(ROWS[dataset][s], d, idx.dim, 1234 + i, dev))
-        shards.append(idx)
+        by_model.setdefault(model_of[s], []).append(i)
+    for m, members in by_model.items():
+        d = WIDTH[m]
+        if mode == "segments" and len(members) > 1:   # one matrix for the sources of this encoder, filled in place
+            seg = SegmentedIndex(d, [ROWS[dataset][sources[i]] for i in members], id_offsets=[i << 40 for i in members], mask_cols=members, device=dev)
+            for j, i in enumerate(members):
+                make(ROWS[dataset][sources[i]], d, seg.dim, 1234 + i, dev, out=seg.rows_of(j))
+                shards[i] = seg.source(j)
+            units.append((seg, members))
+        else:
+            for i in members:
+                idx = FlatIndex(d, device=dev)
+                idx.adopt(make(ROWS[dataset][sources[i]], d, idx.dim, 1234 + i, dev))
+                shards[i] = idx
+                units.append((idx, [i]))
+    units.sort(key=lambda u: u[1][0])
+    for i, s in enumerate(sources):
+        idx, d = shards[i], WIDTH[model_of[s]]
         total_bytes += idx.ntotal * idx.dim * 2
         c = np.zeros(d_max, np.float32)
         c[:d] = idx.centroid().cpu().numpy()[:d]
-        cents.append(c)
+        cents[i] = c
     g = torch.Generator(device=dev)
     g.manual_seed(4321)
     emb = {}
@@ -76,7 +95,7 @@ def main():
     net = CorpusRoutingNN(C.ROUTER_INPUT_DIMENSION[dataset], seed=0)
     router = FoldedRouter.fold(net.state_dict(), np.stack(cents), onehot, len(sources), d_max, [models.index(model_of[s]) for s in sources],
                                C.ROUTER_THRESHOLD[dataset], device=dev)
-    pipe = RetrievalPipeline(shards, list(range(len(sources))), router=router, slots=len(sources))
+    pipe = RetrievalPipeline(shards, list(range(len(sources))), router=router, units=units)
     xq = {i: emb[model_of[s]] for i, s in enumerate(sources)}
 
     def step():
@@ -103,7 +122,9 @@ def main():
         per_source[s] = {"rows": shards[i].ntotal, "dim": shards[i].dim, "ms": round(t[2], 4),
                          "frac_of_8TBps": round(shards[i].ntotal * shards[i].dim * 2 / (t[2] * 1e-3) / 8e12, 4)}
     print(json.dumps({
-        "config": f"{dataset}: {len(sources)} sources at their real row counts and encoder widths on 1 GPU, B={B}, k={k}, router + per-source exact top-k + merge",
+        "config": f"{dataset}: {len(sources)} sources at their real row counts and encoder widths on 1 GPU, B={B}, k={k}, router + "
+                  + ("one segmented search per encoder group" if mode == "segments" else "per-source exact top-k") + " + merge",
+        "search_units": [{"sources": [sources[i] for i in m], "kind": "segments" if isinstance(u, SegmentedIndex) else "source"} for u, m in units],
         "rows_total": int(sum(ROWS[dataset].values())), "corpus_GB": round(total_bytes / 1e9, 2), "median_ms_per_batch": round(med, 3),
         "p10_ms": round(ms[len(ms) // 10], 3), "p90_ms": round(ms[(len(ms) * 9) // 10], 3), "queries_per_s": round(B / med * 1e3, 1),
         "corpus_GBps": round(total_bytes / 1e9 / (med * 1e-3), 1), "frac_of_8TBps": round(total_bytes / (med * 1e-3) / 8e12, 4),

@@ -1,0 +1,124 @@
+"""Service-level throughput of the data-source loop on one MI355X.
+
+    python tools/service_bench.py [rows] [windows_ms ...]          (default: 10_000_000 rows, windows 0.2 0.5 2)
+
+The reference's harness drives concurrency through HTTP (`run_benchmark.py --parallel N`, run_benchmark.py:90-112); every request
+reaches a data source as ONE message `{"id", "query", "embedding": [768 floats]}` (http_server.py:205-209) and is answered with
+`{"query_id", "client_id", "name", "indices", "docs", "scores", "duration"}` (data_source.py:123-131).  Here C closed-loop
+clients (C = 1, 32, 256: each sends its next request when the previous reply is in) call `DataSource.handle_query` of the
+MedRAG-shaped source in process — JSON-encoding every request and reply like the wire does (tests/stub_zmq.py) — against a
+synthetic 10M x 768 fp16 corpus, for each batcher window `RAGROUTE_BATCH_WINDOW_MS`.  Reported: requests per second, p50 / p99
+latency, mean queries per GPU search (how full the batcher's windows are), next to the raw `FlatIndex.search` (numpy in / out,
+no service) at batch 1 / 32 / 256 — what the service could reach if it cost nothing.
+
+Per request the service does what the reference's does (data_source.py:165-194): the search, `metadatas[i]` for the k rows,
+the JSONL text lookup per row; metadata and texts are synthetic (lazy sequences: 10M dicts would only measure Python's heap)."""
+import asyncio
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from ragroute_amd import config
+from ragroute_amd.data_source import DataSource
+from ragroute_amd.flat_index import FlatIndex
+
+
+class LazyMeta:
+    """metadatas.jsonl stand-in: row -> {"index", "source"} (data_source.py:73, 169-170) without 10M dicts on the heap."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return {"index": int(i) % 4096, "source": f"chunk{int(i) % 8}"}
+
+
+def make_corpus(n, d, dev):
+    idx = FlatIndex(d, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    xb = torch.zeros((n, idx.dim), dtype=torch.float16, device=dev)
+    for s in range(0, n, 1 << 20):
+        e = min(n, s + (1 << 20))
+        x = torch.randn((e - s, d), generator=g, device=dev)
+        xb[s:e, :d] = (x / x.norm(dim=1, keepdim=True)).half()
+    idx.adopt(xb)
+    return idx
+
+
+async def closed_loop(ds, queries, clients, seconds):
+    lat, done = [], 0
+    stop_at = time.perf_counter() + seconds
+
+    async def client(c):
+        nonlocal done
+        i = c
+        while time.perf_counter() < stop_at:
+            msg = json.loads(json.dumps({"id": f"q{c}_{i}", "query": "synthetic", "embedding": queries[i % len(queries)]}))
+            t0 = time.perf_counter()
+            reply = await ds.handle_query(msg)
+            json.dumps(reply)                                   # the reply crosses the wire as JSON (data_source.py:132)
+            lat.append(time.perf_counter() - t0)
+            done += 1
+            i += clients
+
+    t0 = time.perf_counter()
+    await asyncio.gather(*[client(c) for c in range(clients)])
+    dt = time.perf_counter() - t0
+    lat.sort()
+    b = ds._batcher
+    return {"clients": clients, "requests": done, "requests_per_s": round(done / dt, 1),
+            "p50_ms": round(lat[len(lat) // 2] * 1e3, 3), "p99_ms": round(lat[min(len(lat) - 1, int(len(lat) * 0.99))] * 1e3, 3),
+            "queries_per_search": round(b.items_run / max(1, b.batches_run), 1), "searches": b.batches_run}
+
+
+def raw_search(idx, queries, batch, seconds):
+    q = np.asarray(queries[:batch], np.float32)
+    idx.search(q, 32)
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        idx.search(q, 32)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"batch": batch, "queries_per_s": round(n * batch / dt, 1), "ms_per_search": round(dt / n * 1e3, 3)}
+
+
+def main():
+    rows = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+    windows = [float(v) for v in sys.argv[2:]] or [0.2, 0.5, 2.0]
+    dev = torch.device("cuda:0")
+    d, k = 768, config.K["medrag"]
+    idx = make_corpus(rows, d, dev)
+    rng = np.random.default_rng(4321)
+    q = rng.standard_normal((1024, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    queries = [row.tolist() for row in q]                        # the wire carries Python float lists (router.py:317-319)
+    out = {"workload": f"{rows} x {d} fp16 rows, medrag-shaped data source (k = {k}), closed-loop clients calling DataSource.handle_query "
+                       "in process, JSON-encoded requests and replies", "raw_FlatIndex_search": [raw_search(idx, q, b, 1.5) for b in (1, 32, 256)],
+           "service": []}
+    for w in windows:
+        for clients in (1, 32, 256):
+            ds = DataSource(0, "medrag", "pubmed")
+            ds.batch_window_ms = w
+            ds.set_index(idx, LazyMeta(rows))
+            ds.cache_jsonl = {f"chunk{c}": [json.dumps({"id": f"c{c}_{i}", "title": f"title {i}", "content": "x" * 200}) for i in range(4096)]
+                              for c in range(8)}
+            res = asyncio.run(closed_loop(ds, queries, clients, 3.0))
+            res["batch_window_ms"] = w
+            out["service"].append(res)
+            print(json.dumps(res), file=sys.stderr, flush=True)
+    best = max((r for r in out["service"] if r["clients"] == 256), key=lambda r: r["requests_per_s"])
+    out["best_window_ms_at_256_clients"] = best["batch_window_ms"]
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
