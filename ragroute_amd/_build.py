@@ -64,7 +64,9 @@ def check_isa(obj_path):
         if not name or not any(k in name.group(1) for k in FIXED_AGPR_KERNELS):
             continue
         seen += 1
-        for key in (".private_segment_fixed_size", ".vgpr_spill_count", ".sgpr_spill_count"):
+        # (.sgpr_spill_count may be non-zero: scalar spills go to lanes of a VGPR the compiler owns - never to the hard-wired AGPRs,
+        # and never to memory while private_segment_fixed_size stays 0)
+        for key in (".private_segment_fixed_size", ".vgpr_spill_count"):
             m = re.search(re.escape(key) + r":\s+(\d+)", block)
             if m and int(m.group(1)) != 0:
                 problems.append(f"{name.group(1)}: {key} = {m.group(1)}")

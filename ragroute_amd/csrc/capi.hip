@@ -94,6 +94,7 @@ double chunk_schedule(double ratio, int k) {
 struct Workspace {
   uint32_t *seg_tile_end, *seg_row_limit, *seg_row_begin, *seg_sel;   // segmented search: device tables written by prep_kernel
   int64_t* seg_id_offset;
+  rr::RangeEntry* ranges;                                             // [kMaxChunks][kMaxSegments] tile runs of the chunk launches
   float* thr;
   uint32_t* list_cnt;
   uint64_t* list;
@@ -117,6 +118,7 @@ Workspace carve(char* base, int k, int grid) {
   w.seg_row_begin = (uint32_t*)take(kMaxSegments * sizeof(uint32_t));
   w.seg_id_offset = (int64_t*)take(kMaxSegments * sizeof(int64_t));
   w.seg_sel = (uint32_t*)take(kQueriesPerBlock * sizeof(uint32_t));
+  w.ranges = (RangeEntry*)take((size_t)kMaxChunks * kMaxSegments * sizeof(RangeEntry));
   w.list_cnt = (uint32_t*)take(kQueriesPerBlock * sizeof(uint32_t));
   w.list = (uint64_t*)take((size_t)kQueriesPerBlock * kMaxK * sizeof(uint64_t));
   w.cand_cnt = (uint32_t*)take((size_t)kQueriesPerBlock * grid * 4 * sizeof(uint32_t));
@@ -188,7 +190,7 @@ size_t rr_flat_search_workspace_bytes(int k) {
 // scanned as one corpus; route_mask then is [nq][mask_stride] with one column per segment (segs->mask_col), id_offset unused.
 static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, const void* xq, int nq, int k, float* D,
                             int64_t* I, int64_t id_offset, void* ws, size_t ws_bytes, const uint8_t* route_mask,
-                            int64_t mask_stride, const float* half_sqnorm, void* stream, const rr::SegHost* segs = nullptr) {
+                            int64_t mask_stride, const float* half_sqnorm, void* stream, rr::SegHost* segs = nullptr) {
   using namespace rr;
   hipStream_t st = (hipStream_t)stream;
   if (k < 1 || k > kMaxK) return fail(RR_ERR_INVALID, "rr_flat_search: k must be in [1, 1024]%s");
@@ -210,6 +212,17 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
   hipError_t e;
 #define RR_CHECK(call, what) do { e = (call); if (e != hipSuccess) return hip_fail(e, what); } while (0)
 
+  if (segs && n_rows > kDenseMaxRows) {
+    // chunk fractions of the segmented schedule: frac[c] = sample share x growth^(c+1), the last one 1 (no sliver of a last chunk)
+    const uint32_t n_sample_tiles = (uint32_t)g_sample_rows / kTileRows;
+    const double ratio = (double)total_tiles / n_sample_tiles, growth = chunk_schedule(ratio, k);
+    double f = growth / ratio;
+    uint32_t c = 0;
+    for (; c + 1 < (uint32_t)kMaxChunks && f * 1.25 < 1.0; ++c, f *= growth) segs->frac[c] = (uint32_t)(f * 4294967296.0);
+    segs->frac[c++] = 0xFFFFFFFFu;
+    segs->n_chunks = c;
+    segs->ranges = w.ranges;
+  }
   const int qpl = scan_queries_per_launch(dim, nq);  // 256, or 128 where only 32 queries per wave stay resident and the batch is small
   for (int qb = 0; qb < nq; qb += qpl) {
     const int nqb = nq - qb < qpl ? nq - qb : qpl;
@@ -228,7 +241,7 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
     a.xb = xb; a.xq = xq_b; a.thr = w.thr; a.cand = w.cand; a.cand_cnt = w.cand_cnt; a.scratch = w.scratch;
     a.dense = w.dense; a.n_rows = (uint32_t)n_rows; a.nq = (uint32_t)nqb; a.dense_ld = kSampleRows; a.cap = cap; a.k = k;
     a.half_sqnorm = half_sqnorm;
-    if (segs) { a.seg_tile_end = w.seg_tile_end; a.seg_row_limit = w.seg_row_limit; a.n_segs = segs->n; }
+    if (segs) a.ties_pass = 1;
     // (per query block: launch_flat_scan picks the kernel from the block's own query count, e.g. the 44-query tail of a 300-query call)
     const int bpw = dtype == kDtypeI8 ? 4 : scan_query_blocks_per_wave(dim, nqb, half_sqnorm != nullptr);
     a.xqs = bpw ? w.xqs : nullptr;
@@ -255,6 +268,28 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
       // insertion work of a long chunk (chunk_schedule).
       const double growth = chunk_schedule((double)total_tiles / n_sample_tiles, k);
       FinalizeArgs fin{D_b, I_b, id_offset, segs ? nullptr : mask_b, mask_stride};
+      if (segs) {
+        // Segmented: chunk c takes the next slice of EVERY segment (seg_cut), reaching the cumulative fraction frac[c] of each, so
+        // that whatever subset of the segments a query is routed to, its rows arrive in geometrically growing portions.  The
+        // launch sizes below and prep_kernel's range tables (already enqueued above with the same SegHost) use one expression.
+        for (uint32_t c = 0; c < segs->n_chunks; ++c) {
+          uint32_t n_launch_tiles = 0, n_ranges = 0;
+          for (uint32_t sg = 0; sg < segs->n; ++sg) {
+            const uint32_t tiles = (segs->row_limit[sg] - segs->row_begin[sg] + kTileRows - 1) / kTileRows;
+            const uint32_t lo = c ? seg_cut(tiles, segs->frac[c - 1]) : 0u, hi = seg_cut(tiles, segs->frac[c]);
+            if (hi > lo) { n_launch_tiles += (hi - lo + 7u) & ~7u; ++n_ranges; }
+          }
+          const bool last = c + 1 == segs->n_chunks;
+          if (n_launch_tiles == 0 && !last) continue;
+          if (n_launch_tiles > 0) {
+            a.tile_first = 0; a.tile_stride = 1; a.n_tiles = n_launch_tiles;
+            a.ranges = w.ranges + (size_t)c * kMaxSegments; a.n_ranges = n_ranges;
+            RR_CHECK(profiled_scan(a, dtype, dim, false, grid, st), "rr_flat_search_segments/scan");
+          }
+          RR_CHECK(launch_compact(s, last ? &fin : nullptr, st), "rr_flat_search_segments/compact");
+          if (last) finalized = true;
+        }
+      } else {
       uint64_t begin = 0;
       double endf = (double)n_sample_tiles * growth;  // in tiles
       while (begin < total_tiles) {
@@ -270,6 +305,7 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
         if (last && !half_sqnorm) finalized = true;
         begin = end;
         endf *= growth;
+      }
       }
     }
     if (!finalized)

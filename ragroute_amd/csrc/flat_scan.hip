@@ -71,9 +71,11 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   const int rho_w = lane >> 3, sig = lane & 7;
   const int f_w = ((rho_w >> 1) & 3) | ((wave & 1) << 2);
   const int c_w = sig ^ f_w;
+  TileCursor dcur;   // the DMA stream's position in the launch's tile runs (segmented search; plain: tile_first + j * tile_stride)
+  cursor_init(a, dcur);
   auto tile_src = [&](uint32_t j) -> const char* {
     if (j >= a.n_tiles) j = a.n_tiles - 1;
-    const uint32_t tile = a.tile_first + j * a.tile_stride;
+    const uint32_t tile = cursor_tile(a, dcur, j);
     uint32_t row = tile * kTileRows + wave * 8 + rho_w;
     row = row < a.n_rows ? row : a.n_rows - 1;
     return (const char*)a.xb + (size_t)row * (D * 2) + c_w * 16;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   const int nb = __builtin_amdgcn_readfirstlane(nblk > wave ? (nblk - wave + 3) >> 2 : 0);
 
   // L2: |x|^2/2 of the 32 rows of tile ordinal jj -> LDS floats [NS*TILE_BYTES + slot*256 ...] (lanes 32..63 duplicate)
-  auto issue_norms = [&](uint32_t jj, int slot_) {
+  auto issue_norms = [&](uint32_t jj, int slot_) {   // (L2 metric: never a segmented search, no cursor)
     if (jj >= a.n_tiles) jj = a.n_tiles - 1;
     uint32_t row = (a.tile_first + jj * a.tile_stride) * kTileRows + (lane & 31);
     row = row < a.n_rows ? row : a.n_rows - 1;
@@ -310,8 +312,10 @@ __global__ __launch_bounds__(256, 1) void flat_scan16h_kernel(const ScanArgs a) 
   }
   float thr[2];
   uint32_t cnt[2], off[2];
-  int seg = -1;                                                        // segmented search (see LaneState4)
-  uint32_t seg_end_tile = a.seg_tile_end ? 0u : 0xFFFFFFFFu, row_limit = a.n_rows;
+  TileCursor dcur, ecur;                                               // segmented search: DMA-stream and epilogue cursors (see TileCursor)
+  cursor_init(a, dcur);
+  cursor_init(a, ecur);
+  uint32_t row_limit = a.n_rows;
   const uint32_t nbuf = gridDim.x * 4;
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan16h_kernel(const ScanArgs a) 
   auto unit_src = [&](uint32_t u) -> const char* {
     if (u >= n_units) u = n_units - 1;
     const uint32_t j = blockIdx.x + (u >> 1) * gridDim.x;
-    const uint32_t tile = a.tile_first + j * a.tile_stride;
+    const uint32_t tile = cursor_tile(a, dcur, j);
     uint32_t row = tile * kTileRows + (u & 1) * 16 + pw * 8 + rho_w;
     row = row < a.n_rows ? row : a.n_rows - 1;
     return (const char*)a.xb + (size_t)row * (D * 2) + c_w * 16 + kpar * 128;
@@ -374,7 +378,6 @@ __global__ __launch_bounds__(256, 1) void flat_scan16h_kernel(const ScanArgs a) 
     if (nslot >= NSLOT) nslot -= NSLOT;
     const char* gn = unit_src(u + AHEAD);
     const uint32_t j = blockIdx.x + (u >> 1) * gridDim.x;
-    const uint32_t row0 = (a.tile_first + j * a.tile_stride) * kTileRows + (u & 1) * 16 + 4 * g;
     if (nb > 0) {
       f32x4 acc[2];
       constexpr int NB = KS2 < 8 ? KS2 : 8;
@@ -414,11 +417,16 @@ __global__ __launch_bounds__(256, 1) void flat_scan16h_kernel(const ScanArgs a) 
         for (int qb = 0; qb < 2; ++qb)
           *(f32x4*)(a.dense + (size_t)(wave * 32 + qb * 16 + col) * a.dense_ld + j * kTileRows + (u & 1) * 16 + 4 * g) = acc[qb];
       } else {
-        if (a.tile_first + j * a.tile_stride >= seg_end_tile) {   // segmented search: the unit's tile has left the wave's segment
-          seg = segment_advance(a, seg, a.tile_first + j * a.tile_stride, seg_end_tile, row_limit);
-#pragma unroll
-          for (int qb = 0; qb < 2; ++qb) thr[qb] = asm_load_f32(a.thr + (size_t)seg * kQueriesPerBlock + wave * 32 + qb * 16 + col);
+        if (j >= ecur.j_end) {   // segmented search: the wave enters another segment's slice (see tile_epilogue16)
+          const RangeEntry e = cursor_advance(a, ecur, j);
+          row_limit = e.row_limit;
+          const uint32_t qi[4] = {(uint32_t)(wave * 32 + col), (uint32_t)(wave * 32 + 16 + col), 0u, 0u};
+          float t4[4];
+          load_thresholds<2>(a, e.seg, qi, t4);
+          thr[0] = t4[0];
+          thr[1] = t4[1];
         }
+        const uint32_t row0 = (a.tile_first + j * a.tile_stride + (uint32_t)ecur.delta) * kTileRows + (u & 1) * 16 + 4 * g;
         const float m0 = max4v(acc[0]), m1 = max4v(acc[1]);
         if (__builtin_amdgcn_ballot_w64(m0 > thr[0] || m1 > thr[1])) {
 #pragma unroll
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan16h_kernel(const ScanArgs a) 
                 const int cn = (int)__shfl(cnt[qb], L, 64);
                 const uint64_t kth = wave_compact(a.cand + (size_t)__builtin_amdgcn_readfirstlane(o), scratch,
                                                   __builtin_amdgcn_readfirstlane(cn), a.k, lane);
-                if (lane == L) { cnt[qb] = a.k; thr[qb] = key_score(kth); }
+                if (lane == L) { cnt[qb] = a.k; thr[qb] = a.ties_pass ? next_below(key_score(kth)) : key_score(kth); }
               }
             }
           }

@@ -251,15 +251,6 @@ __device__ __forceinline__ f32x4 lds_load_f32x4(uint32_t byte_addr) {
   return v;
 }
 
-struct LaneState4 {
-  float thr[4];
-  uint32_t cnt[4], off[4];
-  // segmented search (wave-uniform): the segment the wave's current tile lies in, its first tile past the end, and the first row
-  // past its valid rows.  Plain search: seg_end_tile = ~0 (never reached), row_limit = n_rows.
-  uint32_t seg_end_tile, row_limit;
-  int seg;
-};
-
 // Loads of the rare paths, with their own wait and invisible to hipcc's waitcnt pass: a VMEM load it can see inside a loop that
 // keeps LDS-DMA / prefetched registers in flight makes it put s_waitcnt vmcnt(0) into the hot path (pitfall i).
 // The wait drains the wave's DMA ring too, which is always safe (the counted waits that follow are then met at once).
@@ -270,23 +261,73 @@ __device__ __forceinline__ uint32_t asm_load_u32(const void* p) {
 }
 __device__ __forceinline__ float asm_load_f32(const void* p) { return __uint_as_float(asm_load_u32(p)); }
 
-__device__ __forceinline__ void lane_state_segments_init(const ScanArgs& a, LaneState4& st) {
-  st.seg = -1;
-  st.seg_end_tile = a.seg_tile_end ? 0u : 0xFFFFFFFFu;   // segmented: the first tile enters segment_advance
-  st.row_limit = a.n_rows;
+// ---- segmented search: launch ordinal -> tile --------------------------------------------------------------------------------
+// A chunk launch of a segmented search covers one run of tiles per segment (ScanArgs::ranges).  A workgroup's ordinals only move
+// forward, so each stream of a kernel (DMA issue, query prefetch, epilogue) keeps a wave-uniform cursor: the run it is in, where
+// the run ends and the offset to add.  Plain launches: j_end = ~0 (never reached), delta = 0, and the tile is
+// tile_first + j * tile_stride as before (segmented chunk launches have tile_first = 0, tile_stride = 1).
+struct TileCursor {
+  uint32_t j_end;
+  int32_t delta;
+  int r;
+};
+__device__ __forceinline__ void cursor_init(const ScanArgs& a, TileCursor& c) {
+  c.r = -1;
+  c.delta = 0;
+  c.j_end = a.ranges ? 0u : 0xFFFFFFFFu;
 }
-// The wave's tile has left its segment (a workgroup's tiles only move forward, so this happens at most n_segs times per
-// launch): find the segment of `tile`, its end and its valid-row limit.  Returns the segment; the caller reloads its thresholds
-// from a.thr[seg][query] (+inf for queries not routed there: nothing of them passes the filter).
-__device__ __forceinline__ int segment_advance(const ScanArgs& a, int seg, uint32_t tile, uint32_t& seg_end_tile, uint32_t& row_limit) {
-  uint32_t end;
+// (rare: at most n_ranges times per launch and stream) move to the run holding ordinal j; returns its RangeEntry.
+// The entry comes through the scalar cache (s_load + lgkmcnt(0): the callers sit where the wave's LDS fragment ring is empty), so
+// the DMA ring is NOT drained here.
+__device__ __forceinline__ RangeEntry cursor_advance(const ScanArgs& a, TileCursor& c, uint32_t j) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  RangeEntry e;
   do {
-    ++seg;
-    end = (uint32_t)__builtin_amdgcn_readfirstlane((int)asm_load_u32(a.seg_tile_end + seg));
-  } while (tile >= end && seg + 1 < (int)a.n_segs);
-  seg_end_tile = end;
-  row_limit = (uint32_t)__builtin_amdgcn_readfirstlane((int)asm_load_u32(a.seg_row_limit + seg));
-  return seg;
+    ++c.r;
+    u32x4 v;
+    const RangeEntry* p = a.ranges + c.r;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    e.j_end = v[0];
+    e.delta = (int32_t)v[1];
+    e.seg = v[2];
+    e.row_limit = v[3];
+  } while (j >= e.j_end);   // (the last run's j_end is ~0: ordinals past the launch's end - streams run ahead - stay in it)
+  c.j_end = e.j_end;
+  c.delta = e.delta;
+  return e;
+}
+// the lane's thresholds of segment `seg` for up to four of its queries: all loads in flight together, ONE wait (it drains the
+// wave's DMA ring: once per segment slice and launch)
+template <int N>
+__device__ __forceinline__ void load_thresholds(const ScanArgs& a, uint32_t seg, const uint32_t (&qi)[4], float (&thr)[4]) {
+  const float* base = a.thr + (size_t)seg * kQueriesPerBlock;
+  const float *p0 = base + qi[0], *p1 = base + qi[N > 1 ? 1 : 0], *p2 = base + qi[N > 2 ? 2 : 0], *p3 = base + qi[N > 3 ? 3 : 0];
+  float t0, t1, t2, t3;
+  asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %5, off\n\tglobal_load_dword %2, %6, off\n\t"
+               "global_load_dword %3, %7, off\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+  thr[0] = t0;
+  if (N > 1) thr[1] = t1;
+  if (N > 2) thr[2] = t2;
+  if (N > 3) thr[3] = t3;
+}
+__device__ __forceinline__ uint32_t cursor_tile(const ScanArgs& a, TileCursor& c, uint32_t j) {
+  if (j >= c.j_end) (void)cursor_advance(a, c, j);
+  return a.tile_first + j * a.tile_stride + (uint32_t)c.delta;
+}
+
+struct LaneState4 {
+  float thr[4];
+  uint32_t cnt[4], off[4];
+  // segmented search (wave-uniform): the epilogue's cursor, and the first row past the valid rows of the segment it is in.
+  // Plain search: row_limit = n_rows.
+  TileCursor cur;
+  uint32_t row_limit;
+};
+
+__device__ __forceinline__ void lane_state_segments_init(const ScanArgs& a, LaneState4& st) {
+  cursor_init(a, st.cur);
+  st.row_limit = a.n_rows;
 }
 
 __device__ __forceinline__ float max4v(const f32x4& v) { return max4(v[0], v[1], v[2], v[3]); }
@@ -297,7 +338,6 @@ __device__ __forceinline__ float max4v(const f32x4& v) { return max4(v[0], v[1],
 template <bool DENSE, int NQB, int QPW = 64, bool INLINE_COMPACT = false, int WAVES = 256 / QPW, bool DEAL = false>
 __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& st, f32x4 (&acc)[2][4], uint32_t j, int lane, int wave) {
   const int col = lane & 15, g = lane >> 4;
-  const uint32_t tile = a.tile_first + j * a.tile_stride;
   if (DENSE) {
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
@@ -307,12 +347,16 @@ __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& s
     }
     return;
   }
-  if (tile >= st.seg_end_tile) {   // segmented search only (plain: seg_end_tile = ~0); wave-uniform, a handful of times per launch
-    st.seg = segment_advance(a, st.seg, tile, st.seg_end_tile, st.row_limit);
+  if (j >= st.cur.j_end) {   // segmented search only (plain: j_end = ~0); wave-uniform, once per segment and launch: the wave enters
+    // another segment's slice - its valid-row limit and its thresholds (+inf for queries not routed to it) replace the lane's
+    const RangeEntry e = cursor_advance(a, st.cur, j);
+    st.row_limit = e.row_limit;
+    uint32_t qi[4];
 #pragma unroll
-    for (int qb = 0; qb < NQB; ++qb)
-      st.thr[qb] = asm_load_f32(a.thr + (size_t)st.seg * kQueriesPerBlock + (DEAL ? (qb * 4 + wave) * 16 + col : wave * QPW + qb * 16 + col));
+    for (int qb = 0; qb < 4; ++qb) qi[qb] = DEAL ? (qb * 4 + wave) * 16 + col : wave * QPW + (qb < NQB ? qb : 0) * 16 + col;
+    load_thresholds<NQB>(a, e.seg, qi, st.thr);
   }
+  const uint32_t tile = a.tile_first + j * a.tile_stride + (uint32_t)st.cur.delta;
 #ifndef RR_EPILOGUE_MASKS
 #define RR_EPILOGUE_MASKS 0   // 1: the insertion path branches on wave masks made by the filter instead of re-deriving them per group (measured: headline -0.4 %, config 2 +0.8 %, i.e. noise; off)
 #endif
@@ -376,7 +420,7 @@ __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& s
         uint64_t* buf = a.cand + (size_t)__builtin_amdgcn_readfirstlane(off);
         const uint64_t kth = INLINE_COMPACT ? wave_compact_inl(buf, scratch, __builtin_amdgcn_readfirstlane(cnt), a.k, lane)
                                             : wave_compact(buf, scratch, __builtin_amdgcn_readfirstlane(cnt), a.k, lane);
-        if (lane == L) { st.cnt[qb] = a.k; st.thr[qb] = key_score(kth); }
+        if (lane == L) { st.cnt[qb] = a.k; st.thr[qb] = a.ties_pass ? next_below(key_score(kth)) : key_score(kth); }
       }
     }
     // Inlined, the compaction's own global loads are visible to hipcc's waitcnt pass: without a wait IT can see, it treats

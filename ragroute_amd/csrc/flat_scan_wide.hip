@@ -60,15 +60,36 @@ __device__ __forceinline__ void vm_wait_tied8(F& r0, F& r1, F& r2, F& r3, F& r4,
 #ifndef RR_WIDE_KROT
 #define RR_WIDE_KROT 5   // 0: every group starts at column 0 (A/B)
 #endif
-__device__ __forceinline__ int wide_group_rotation(const ScanArgs& a, uint32_t grp, int tiles_per_group, int KG) {
+__device__ __forceinline__ bool wide_rotates(int KG) { return RR_WIDE_KROT && KG > 24 && !(KG & 31); }
+// rotation of the 256-row group whose first tile is `tile` (global: a function of the rows alone)
+__device__ __forceinline__ int wide_rotation_of_tile(uint32_t tile, int KG) {
   // only where the row pitch is a multiple of 4 KiB (d = 2048, 4096, 6144, 8192): other pitches spread over the channels by
   // themselves (d = 1792: one query 0.845 without, 0.80 with; d = 3072 and 5120: no gain), and d <= 1536 is also served by the
   // half-resident kernel, which has no rotation.  Rows wider than 4096 rotate within a window of 64 columns: with the whole K range
   // in flight the 4 MB query block of d = 8192 no longer fits an XCD's L2 (256 queries -2.9 %); windowed: one query 0.79 -> 0.83
   // (d = 8192) and 0.77 -> 0.82 (d = 6144), 256 queries unchanged.
-  if (!RR_WIDE_KROT || KG <= 24 || (KG & 31)) return 0;
-  const uint32_t m = (a.tile_first + grp * (uint32_t)tiles_per_group * a.tile_stride) >> 3;
-  return (int)((m * (uint32_t)RR_WIDE_KROT) % (uint32_t)(KG > 64 ? 64 : KG));
+  if (!wide_rotates(KG)) return 0;
+  return (int)(((tile >> 3) * (uint32_t)RR_WIDE_KROT) % (uint32_t)(KG > 64 ? 64 : KG));
+}
+// ... of launch group `grp` (groups of tiles_per_group launch ordinals).  Segmented chunk launches (rotating widths only, i.e. never
+// FeB4RAG's or MedRAG's encoder groups): the run holding the group is looked up from the start of the launch's table each time -
+// a few scalar loads per 256-row group - rather than with a third cursor, whose SGPRs the wide-row kernels do not have to spare.
+__device__ __forceinline__ int wide_group_rotation(const ScanArgs& a, uint32_t grp, int tiles_per_group, int KG) {
+  if (!wide_rotates(KG)) return 0;
+  const uint32_t j = grp * (uint32_t)tiles_per_group;
+  uint32_t tile = a.tile_first + j * a.tile_stride;
+  if (a.ranges) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 v;
+    uint32_t r = 0;
+    do {
+      const RangeEntry* p = a.ranges + r;
+      asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+      ++r;
+    } while (j >= v[0]);   // (the last run's j_end is ~0)
+    tile += v[1];
+  }
+  return wide_rotation_of_tile(tile, KG);
 }
 __device__ __forceinline__ int wide_rotated(int kg, int rot, int KG) { return kg + rot >= KG ? kg + rot - KG : kg + rot; }
 
@@ -380,16 +401,19 @@ __global__ __launch_bounds__(256, 1) void flat_scan_wide_pd_kernel(const ScanArg
   uint32_t voff[NT];
   int drot = 0;                            // K rotation of the DMA stream's group (wide_group_rotation)
 
+  TileCursor dcur;                         // segmented search: cursor of the DMA stream (see TileCursor)
+  cursor_init(a, dcur);
   auto dma_new_group = [&](uint32_t grp) {
     if (grp >= n_groups) return;           // the stream runs ahead of the last group: it re-reads that one (valid memory, never used)
-    const uint32_t row_base = (a.tile_first + grp * NT * a.tile_stride) * kTileRows;   // < n_rows: the group's first tile exists
+    const uint32_t tile0 = cursor_tile(a, dcur, grp * NT);      // (a group never straddles two runs: runs are whole groups)
+    const uint32_t row_base = tile0 * kTileRows;   // < n_rows: the group's first tile exists
     dbase = (const char*)a.xb + (size_t)row_base * row_bytes;
-    drot = wide_group_rotation(a, grp, NT, KG);
+    drot = wide_rotation_of_tile(tile0, KG);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       uint32_t j = grp * NT + t;
       j = j < n_tiles ? j : n_tiles - 1;
-      uint32_t row = (a.tile_first + j * a.tile_stride) * kTileRows + wave * 8 + rho_w;
+      uint32_t row = (a.tile_first + j * a.tile_stride + (uint32_t)dcur.delta) * kTileRows + wave * 8 + rho_w;
       row = row < a.n_rows ? row : a.n_rows - 1;
       voff[t] = (row - row_base) * (uint32_t)row_bytes + c_w * 16;   // < 256 rows x 16 KB
     }
@@ -705,16 +729,19 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
   const char* dbase = (const char*)a.xb;
   uint32_t voff[NPW];
   int drot = 0;
+  TileCursor dcur;                         // segmented search: cursor of the DMA stream
+  cursor_init(a, dcur);
   auto dma_new_group = [&](uint32_t grp) {
     if (grp >= n_groups) return;
-    const uint32_t row_base = (a.tile_first + grp * NT * a.tile_stride) * kTileRows;
+    const uint32_t tile0 = cursor_tile(a, dcur, grp * NT);
+    const uint32_t row_base = tile0 * kTileRows;
     dbase = (const char*)a.xb + (size_t)row_base * row_bytes;
-    drot = wide_group_rotation(a, grp, NT, KG);
+    drot = wide_rotation_of_tile(tile0, KG);
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
       uint32_t j = grp * NT + tbase + i;
       j = j < n_tiles ? j : n_tiles - 1;
-      uint32_t row = (a.tile_first + j * a.tile_stride) * kTileRows + oct * 8 + rho_w;
+      uint32_t row = (a.tile_first + j * a.tile_stride + (uint32_t)dcur.delta) * kTileRows + oct * 8 + rho_w;
       row = row < a.n_rows ? row : a.n_rows - 1;
       voff[i] = (row - row_base) * (uint32_t)row_bytes + c_w * 16;
     }
@@ -981,6 +1008,7 @@ static hipError_t launch_scan_wide_t(const ScanArgs& a, int D, bool dense, int g
 #undef RR_LAUNCH_8
   }
   if (pd == 0) {
+    if (a.ranges) return hipErrorNotSupported;   // RR_WIDE_PD=0 (A/B of the round-1 kernel): plain searches only
     if (l2) { if (dense) RR_LAUNCH_KERNEL(flat_scan_wide_kernel<T, true, true>) else RR_LAUNCH_KERNEL(flat_scan_wide_kernel<T, false, true>) }
     if (dense) RR_LAUNCH_KERNEL(flat_scan_wide_kernel<T, true, false>) else RR_LAUNCH_KERNEL(flat_scan_wide_kernel<T, false, false>)
   }

@@ -48,6 +48,33 @@ __host__ __device__ inline uint64_t make_key(float s, uint32_t id) {
 __host__ __device__ inline float key_score(uint64_t k) { return unord_f32((uint32_t)(k >> 32)); }
 __host__ __device__ inline uint32_t key_id(uint64_t k) { return 0xFFFFFFFFu - (uint32_t)k; }
 
+// largest float strictly below x (x finite or -inf); s > next_below(t)  <=>  s >= t
+__host__ __device__ inline float next_below(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (x == -__builtin_inff()) return x;
+  uint32_t b = __float_as_uint(x);
+  if ((b & 0x7FFFFFFFu) == 0) return __uint_as_float(0x80000001u);
+  return __uint_as_float((b & 0x80000000u) ? b + 1 : b - 1);
+#else
+  union { float f; uint32_t u; } cv; cv.f = x;
+  if (x < 0 && x * 2 == x) return x;
+  if ((cv.u & 0x7FFFFFFFu) == 0) { cv.u = 0x80000001u; return cv.f; }
+  cv.u = (cv.u & 0x80000000u) ? cv.u + 1 : cv.u - 1;
+  return cv.f;
+#endif
+}
+
+// ---- segmented search: which tiles of a segment a chunk launch covers ------------------------------------------------------
+// Every chunk takes the next slice of EVERY segment - tiles [seg_cut(t, frac[c-1]), seg_cut(t, frac[c])) of a segment of t tiles,
+// frac a 2^-32 fixed-point fraction growing geometrically to 1 - so that a query routed to any subset of the segments sees its
+// own rows arrive in geometrically growing portions (the schedule the exact-selection cost model assumes) whatever the router
+// selected.  Cuts are whole 256-row groups (the wide-row kernels' unit).  Host (launch sizes) and device (prep_kernel's range
+// tables) evaluate the same integer expression.
+__host__ __device__ inline uint32_t seg_cut(uint32_t tiles, uint32_t frac32) {
+  if (frac32 == 0xFFFFFFFFu) return tiles;
+  return (uint32_t)((((uint64_t)tiles * frac32) >> 32) & ~7ull);
+}
+
 // candidate-buffer capacity per (workgroup, query, lane-half) for a given k
 __host__ __device__ inline int cand_cap_for_k(int k) {
   int c = 2 * k;

@@ -7,6 +7,11 @@
 namespace rr {
 
 constexpr int kMaxSegments = 32;   // RR_MAX_SEGMENTS
+constexpr int kMaxChunks = 12;     // scan launches of one search after the bootstrap (chunk_schedule picks <= 8)
+
+// One contiguous run of tiles inside a chunk launch of a segmented search: launch ordinals [previous j_end, j_end) map to tiles
+// j + delta, all in segment `seg` whose valid rows end at row_limit.  A launch has one entry per segment with a non-empty slice.
+struct RangeEntry { uint32_t j_end; int32_t delta; uint32_t seg; uint32_t row_limit; };
 
 // Segmented search (rr_flat_search_segments): one matrix holds several data sources that receive the same query block.  The
 // scan walks the whole matrix as one corpus of "virtual" rows; these device tables (written by prep_kernel) say which rows
@@ -26,9 +31,9 @@ struct ScanArgs {
   const void* xq;       // [nq][D] queries, same dtype
   const void* xqs;      // the same queries in MFMA-fragment order (prep kernel): [wave 4][block 4 or 2][k slice D/32][lane 64][8 elements] (wide rows: 16 blocks)
   const float* thr;     // [256] strict thresholds (filter mode); segmented: [n_segs][256], +inf where the query is not routed to the segment
-  const uint32_t* seg_tile_end;   // segmented search: SegTables::tile_end / row_limit (nullptr: plain search)
-  const uint32_t* seg_row_limit;
-  uint32_t n_segs;
+  const RangeEntry* ranges;   // segmented search, chunk launches: the launch's tile runs (tile_first = 0, tile_stride = 1); nullptr otherwise
+  uint32_t n_ranges;
+  uint32_t ties_pass;         // segmented search: rows are not scanned in ascending id order, so a refreshed threshold must let ties pass
   uint64_t* cand;       // [256][grid*2][cap] candidate keys (filter mode)
   uint32_t* cand_cnt;   // [256][grid*2]
   uint64_t* scratch;    // [grid*4][cap] per-wave compaction scratch
@@ -66,6 +71,9 @@ struct SelectArgs {
 // segs != nullptr: also writes the device segment tables (a.seg points at them) and the per-query selection bits from the route mask
 struct SegHost {                      // by value in prep_kernel's kernarg
   uint32_t n;
+  uint32_t n_chunks;                  // chunk launches after the bootstrap, and the cumulative fraction each one reaches
+  uint32_t frac[kMaxChunks];
+  RangeEntry* ranges;                 // device [kMaxChunks][kMaxSegments], written by prep_kernel
   uint32_t tile_end[kMaxSegments], row_limit[kMaxSegments], row_begin[kMaxSegments];
   int32_t mask_col[kMaxSegments];
   int64_t id_offset[kMaxSegments];

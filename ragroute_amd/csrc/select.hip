@@ -14,14 +14,6 @@
 
 namespace rr {
 
-__device__ __forceinline__ float next_below(float x) {
-  // largest float strictly below x (x finite or -inf); s > next_below(t)  <=>  s >= t
-  if (x == -__builtin_inff()) return x;
-  uint32_t b = __float_as_uint(x);
-  if ((b & 0x7FFFFFFFu) == 0) return __uint_as_float(0x80000001u);
-  return __uint_as_float((b & 0x80000000u) ? b + 1 : b - 1);
-}
-
 // ---- segmented search helpers ---------------------------------------------------------------------------------------------
 // segment of a virtual row (<= 32 segments: a linear walk over the tile ends)
 __device__ __forceinline__ int seg_of_row(const SegTables& t, uint32_t row) {
@@ -39,11 +31,14 @@ __device__ __forceinline__ int64_t seg_result_id(const SegTables& t, uint32_t ro
   const int s = seg_of_row(t, row);
   return t.id_offset[s] + (int64_t)(row - t.row_begin[s]);
 }
-// publish a query's threshold: plain search one value; segmented one per segment, +inf where the query is not routed
+// publish a query's threshold after a compaction (v = score of its k-th best so far): plain search one value, strict — every
+// later row has a larger id, so a tie loses; segmented one per segment (+inf where the query is not routed), and ties PASS: the
+// slices of the segments are scanned interleaved, so a later row can tie with a smaller id.
 __device__ __forceinline__ void publish_thr(const SelectArgs& a, uint32_t q, float v) {
   if (a.seg.n == 0) { a.thr[q] = v; return; }
   const uint32_t bits = a.seg.sel[q];
-  for (uint32_t s = 0; s < a.seg.n; ++s) a.thr[s * kQueriesPerBlock + q] = ((bits >> s) & 1u) ? v : __builtin_inff();
+  const float t = next_below(v);
+  for (uint32_t s = 0; s < a.seg.n; ++s) a.thr[s * kQueriesPerBlock + q] = ((bits >> s) & 1u) ? t : __builtin_inff();
 }
 
 // One launch in front of every search: per-query state, and the query block copied into the order in which the query-resident scan
@@ -65,6 +60,22 @@ __global__ __launch_bounds__(256) void prep_kernel(SelectArgs a, const uint4* __
         const_cast<uint32_t*>(a.seg.row_limit)[q] = segs.row_limit[q];
         const_cast<uint32_t*>(a.seg.row_begin)[q] = segs.row_begin[q];
         const_cast<int64_t*>(a.seg.id_offset)[q] = segs.id_offset[q];
+      }
+      if (q < segs.n_chunks) {   // thread c: the tile runs of chunk launch c (one per segment with a non-empty slice; see seg_cut)
+        RangeEntry* out = segs.ranges + (size_t)q * kMaxSegments;
+        RangeEntry* const first = out;
+        uint32_t j = 0;
+        for (uint32_t s = 0; s < segs.n; ++s) {
+          const uint32_t base = segs.row_begin[s] / kTileRows;
+          const uint32_t tiles = (segs.row_limit[s] - segs.row_begin[s] + kTileRows - 1) / kTileRows;
+          const uint32_t lo = q ? seg_cut(tiles, segs.frac[q - 1]) : 0u, hi = seg_cut(tiles, segs.frac[q]);
+          if (hi > lo) {
+            const uint32_t len = (hi - lo + 7u) & ~7u;   // whole groups: the pad is the segment's alignment gap (rows >= row_limit)
+            j += len;
+            *out++ = RangeEntry{j, (int32_t)(base + lo) - (int32_t)(j - len), s, segs.row_limit[s]};
+          }
+        }
+        if (out != first) out[-1].j_end = 0xFFFFFFFFu;   // the cursors stop at the last run without knowing how many there are
       }
       uint32_t bits = 0;
       if (q < a.nq)
@@ -161,7 +172,10 @@ __global__ __launch_bounds__(1024) void dense_select_kernel(SelectArgs a) {
   if (threadIdx.x == 0) fill_s = 0;
   const uint32_t kth = radix_select_kth<PER>(ordk, (uint32_t)a.k, hist, sel);  // ends with a barrier
   if (BOOTSTRAP) {
-    if (threadIdx.x == 0 && kth != 0 && a.k <= n) publish_thr(a, q, next_below(unord_f32(kth)));
+    if (threadIdx.x == 0 && kth != 0 && a.k <= n) {   // (sample rows may tie with the k-th: they pass in both modes)
+      if (a.seg.n == 0) a.thr[q] = next_below(unord_f32(kth));
+      else publish_thr(a, q, unord_f32(kth));
+    }
     return;
   }
   // kth == 0: fewer than k valid rows -> keep every valid one
