@@ -323,7 +323,7 @@ def test_more_than_one_query_block_at_half_resident_widths(gpu, d, nq):
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
 
 
-@pytest.mark.parametrize("d", [2048, 4096, 1792, 6144])
+@pytest.mark.parametrize("d", [2048, 4096, 1792, 6144, 8192])
 def test_wide_row_scores_do_not_depend_on_batch_size_or_k(gpu, d):
     """Rows wider than 1536 walk their K loop in a rotated order that is a function of the global 256-row group alone
     (flat_scan_wide.hip): the same (query, row) must score bit-identically whatever kernel instance (1 query, 17, 256), chunk
@@ -334,7 +334,8 @@ def test_wide_row_scores_do_not_depend_on_batch_size_or_k(gpu, d):
     xb = half_round(rng.standard_normal((n, d)).astype(np.float32) / np.sqrt(d))
     xq = half_round(rng.standard_normal((256, d)).astype(np.float32))
     idx = _index(gpu, xb, d)
-    D100, I100 = idx.search(xq, 100)
+    D100, I100 = idx.search(xq, 100)            # k = 100: the sample launch + 2 chunk launches (capi.hip chunk_schedule)
+    assert all(len(set(r.tolist())) == 100 for r in I100), "a row was returned twice"   # (a row scoring differently in two launches could be)
     D10, I10 = idx.search(xq, 10)
     assert np.array_equal(I10, I100[:, :10]) and np.array_equal(D10, D100[:, :10])
     for sub in (1, 17, 130):

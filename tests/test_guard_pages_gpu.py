@@ -22,6 +22,10 @@ def _flush_to_end(t, dev):
     nbytes = t.numel() * t.element_size()
     total = max(12 * (1 << 20), -(-nbytes // SEG) * SEG + SEG) // SEG * SEG   # > 10 MiB: a segment of its own
     buf = torch.empty(total, dtype=torch.uint8, device=dev)
+    # the guard only guards if the allocation really ends where its device segment ends (another allocator configuration - e.g.
+    # expandable segments - could map a neighbour right behind it and the test would pass vacuously)
+    segs = [sg for sg in torch.cuda.memory_snapshot() if sg["address"] <= buf.data_ptr() < sg["address"] + sg["total_size"]]
+    assert len(segs) == 1 and segs[0]["address"] + segs[0]["total_size"] == buf.data_ptr() + total, "guard layout: the buffer does not end its segment"
     view = buf[total - nbytes:].view(t.dtype).view(t.shape)
     view.copy_(t)
     return buf, view
@@ -52,19 +56,58 @@ def _run_cases(dev, cases):
         del keep_b
 
 
+def _run_segmented(dev):
+    from ragroute_amd import _lib
+    from ragroute_amd.flat_index import SegmentedIndex
+    from tests.test_segments_gpu import oracle_chain
+    rng = np.random.default_rng(23)
+    for d, rows, nqs in [(768, [20_000, 333, 13_001], (1, 256)), (1024, [9_000, 17_777], (100, 256)), (4096, [9_001, 5_003], (3, 256))]:
+        parts = [int_data(rng, n, d) for n in rows]
+        seg = SegmentedIndex(d, rows, device=dev)
+        host = torch.zeros((seg.n_rows_total, seg.dim), dtype=torch.float16)
+        for s_, p in enumerate(parts):
+            host[seg.begins[s_]: seg.begins[s_] + rows[s_], :d] = torch.from_numpy(p).half()
+        keep_b, arena = _flush_to_end(host, dev)
+        seg._xb = arena                                       # the matrix now ends with its device segment
+        for nq in nqs:
+            xq = int_data(rng, nq, d)
+            xq_h = torch.zeros((nq, seg.dim), dtype=torch.float16)
+            xq_h[:, :d] = torch.from_numpy(xq).half()
+            keep_q, xq_dev = _flush_to_end(xq_h, dev)
+            mask = torch.from_numpy(rng.integers(0, 2, size=(nq, len(rows))).astype(np.uint8)).to(dev)
+            D, I = seg.search_prepared(xq_dev, 10, route_mask=mask)
+            torch.cuda.synchronize()
+            Dr, Ir = oracle_chain(parts, xq, 10, mask.cpu().numpy().astype(bool))
+            assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr), (d, rows, nq)
+            del keep_q
+        del keep_b
+
+
 CASES = [(768, 33_000, (1, 4, 100, 256)), (384, 20_011, (3, 256)), (1024, 40_000, (1, 4, 128, 129, 256)),
          (1536, 20_000, (7, 200)), (2048, 30_000, (1, 4, 17, 256)), (4096, 12_345, (1, 5, 256))]
 
 
+def _in_child(code, extra_env=None):
+    """An over-read is a GPU fault that takes the process down: run the guard layout in a child, so that it fails ONE test
+    instead of aborting the suite (and so that RR_WIDE_WAVES, read once per process, can be forced)."""
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), **(extra_env or {}))
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "ok" in res.stdout, (res.returncode, res.stdout[-500:], res.stderr[-2000:])
+
+
 def test_no_read_past_the_end_of_corpus_or_queries(gpu):
-    _run_cases(gpu, CASES)
+    _in_child("import torch, tests.test_guard_pages_gpu as t; t._run_cases(torch.device('cuda:0'), t.CASES); print('ok')")
+
+
+def test_no_read_past_the_end_segmented_search(gpu):
+    """The same layout for rr_flat_search_segments: the matrix of three sources ends flush against unmapped pages (the last
+    run of a chunk launch is padded to whole 256-row groups in ordinal space: the pad must clamp, not read on)."""
+    _in_child("import torch, tests.test_guard_pages_gpu as t; t._run_segmented(torch.device('cuda:0')); print('ok')")
 
 
 @pytest.mark.parametrize("waves", ["4", "8"])
 def test_no_read_past_the_end_both_wide_row_flavours(gpu, waves):
     """RR_WIDE_WAVES is read once per process: the forced flavours run in a child process."""
-    code = ("import torch, tests.test_guard_pages_gpu as t; "
-            "t._run_cases(torch.device('cuda:0'), [(1024, 40_000, (200, 256)), (2048, 30_000, (1, 4, 17, 256)), (4096, 12_345, (1, 5, 256))]); print('ok')")
-    env = dict(os.environ, RR_WIDE_WAVES=waves, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0 and "ok" in res.stdout, res.stderr[-2000:]
+    _in_child("import torch, tests.test_guard_pages_gpu as t; "
+              "t._run_cases(torch.device('cuda:0'), [(1024, 40_000, (200, 256)), (2048, 30_000, (1, 4, 17, 256)), (4096, 12_345, (1, 5, 256))]); print('ok')",
+              {"RR_WIDE_WAVES": waves})

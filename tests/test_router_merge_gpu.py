@@ -430,3 +430,28 @@ def test_router_batched_matrix_core_form_vs_oracle(gpu, dataset, nq):
         assert np.abs(L[i] - want).max() < LOGIT_TOL, (i, np.abs(L[i] - want).max())
         off = np.abs(want - boundary) > LOGIT_TOL
         assert np.array_equal(M[i][off], (want > boundary)[off])
+
+
+@pytest.mark.parametrize("dataset", ["feb4rag", "wikipedia"])
+def test_router_decisions_do_not_depend_on_how_many_requests_shared_the_window(gpu, dataset):
+    """The router service coalesces concurrent requests (router.py: QueryBatcher, up to 256 per window); windows of fewer than 32
+    queries take the latency-oriented kernel, larger ones the matrix-core form, which sums fc1 in another order.  The same query must
+    get the same answer whatever the load: logits of the two forms within LOGIT_TOL of each other (both are within LOGIT_TOL of the
+    reference's), and identical source masks wherever the logit is further than LOGIT_TOL from the decision boundary — the only
+    place where the reference itself (one query per forward, router.py:207-219) and either form may differ."""
+    r, case = _router(dataset, 35)
+    rng = np.random.default_rng(5)
+    dims = {m: len(v) for m, v in case["queries"][0].items()}
+    nq = 256
+    batch = {m: rng.standard_normal((nq, dm)).astype(np.float32) for m, dm in dims.items()}
+    xq = r.pack_queries(batch)
+    L_big, M_big = r.route_batch(xq)                       # matrix-core form
+    thr = 0.5
+    boundary = float(np.log(thr / (1 - thr)))
+    for size in (1, 7, 31, 32, 100):                        # windows of other sizes, the same queries
+        for start in (0, 64, nq - size):
+            L, M = r.route_batch(xq[start:start + size].contiguous())
+            dl = (L - L_big[start:start + size]).abs().max().item()
+            assert dl < LOGIT_TOL, (size, start, dl)
+            off = (L_big[start:start + size] - boundary).abs() > LOGIT_TOL
+            assert torch.equal(M[off], M_big[start:start + size][off])
