@@ -125,6 +125,7 @@ class DataSource:
         self.mmlu_titles, self.mmlu_texts = [], []
         self.faiss_indexes = None
         self.cache_jsonl = {}
+        self._parsed_docs = {}
         self._batcher = None
         self.batch_window_ms = float(os.environ.get("RAGROUTE_BATCH_WINDOW_MS", 2.0))
 
@@ -170,13 +171,19 @@ class DataSource:
         return D, I, metadatas, single
 
     def _medrag_idx2txt(self, indices):
+        """data_source.py:166-183: the JSONL line `index` of chunk/{source}.jsonl, parsed.  A batched search looks up nq * k lines
+        per window, so each line is parsed once and kept (the reference re-parses it on every hit); callers get their own copy."""
         results = []
         for i in indices:
             source, index = i["source"], i["index"]
             if source not in self.cache_jsonl:
                 with open(os.path.join(self.dataset_dir, self.name, "chunk", f"{source}.jsonl"), "r") as file:
                     self.cache_jsonl[source] = file.read().strip().split("\n")
-            results.append(json.loads(self.cache_jsonl[source][index]))
+            parsed = self._parsed_docs.setdefault(source, {})
+            doc = parsed.get(index)
+            if doc is None:
+                doc = parsed[index] = json.loads(self.cache_jsonl[source][index])
+            results.append(dict(doc) if isinstance(doc, dict) else doc)
         return results
 
     def retrieve_docs_medrag(self, query_embed, k):

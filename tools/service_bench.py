@@ -54,18 +54,34 @@ def make_corpus(n, d, dev):
     return idx
 
 
-async def closed_loop(ds, queries, clients, seconds):
+async def closed_loop(ds, queries, clients, seconds, wire="json"):
+    """wire = "json": every request and reply is JSON-encoded and decoded in this (the event loop's) thread, as pyzmq's
+    send_json / recv_json do in the reference; "objects": the same messages passed as Python objects (embedding = float32 array) -
+    what the batcher and the data source sustain when the transport costs nothing."""
     lat, done = [], 0
     stop_at = time.perf_counter() + seconds
+    work = {"s": 0.0}
+    inner = ds.retrieve_batch
+
+    def timed_batch(embeddings, k=None):                        # the worker thread's share: decode, search, metadata, texts
+        t0 = time.perf_counter()
+        out = inner(embeddings, k)
+        work["s"] += time.perf_counter() - t0
+        return out
+
+    ds.retrieve_batch = timed_batch
 
     async def client(c):
         nonlocal done
         i = c
         while time.perf_counter() < stop_at:
-            msg = json.loads(json.dumps({"id": f"q{c}_{i}", "query": "synthetic", "embedding": queries[i % len(queries)]}))
+            msg = {"id": f"q{c}_{i}", "query": "synthetic", "embedding": queries[i % len(queries)]}
             t0 = time.perf_counter()
+            if wire == "json":
+                msg = json.loads(json.dumps(msg))               # http_server.py:205-209 -> data_source.py:102
             reply = await ds.handle_query(msg)
-            json.dumps(reply)                                   # the reply crosses the wire as JSON (data_source.py:132)
+            if wire == "json":
+                json.dumps(reply)                               # the reply crosses the wire as JSON (data_source.py:132)
             lat.append(time.perf_counter() - t0)
             done += 1
             i += clients
@@ -75,7 +91,8 @@ async def closed_loop(ds, queries, clients, seconds):
     dt = time.perf_counter() - t0
     lat.sort()
     b = ds._batcher
-    return {"clients": clients, "requests": done, "requests_per_s": round(done / dt, 1),
+    return {"clients": clients, "wire": wire, "requests": done, "requests_per_s": round(done / dt, 1),
+            "worker_ms_per_search": round(work["s"] / max(1, b.batches_run) * 1e3, 3),
             "p50_ms": round(lat[len(lat) // 2] * 1e3, 3), "p99_ms": round(lat[min(len(lat) - 1, int(len(lat) * 0.99))] * 1e3, 3),
             "queries_per_search": round(b.items_run / max(1, b.batches_run), 1), "searches": b.batches_run}
 
@@ -101,22 +118,25 @@ def main():
     q = rng.standard_normal((1024, d)).astype(np.float32)
     q /= np.linalg.norm(q, axis=1, keepdims=True)
     queries = [row.tolist() for row in q]                        # the wire carries Python float lists (router.py:317-319)
+    arrays = [row.copy() for row in q]
     out = {"workload": f"{rows} x {d} fp16 rows, medrag-shaped data source (k = {k}), closed-loop clients calling DataSource.handle_query "
                        "in process, JSON-encoded requests and replies", "raw_FlatIndex_search": [raw_search(idx, q, b, 1.5) for b in (1, 32, 256)],
            "service": []}
-    for w in windows:
-        for clients in (1, 32, 256):
-            ds = DataSource(0, "medrag", "pubmed")
-            ds.batch_window_ms = w
-            ds.set_index(idx, LazyMeta(rows))
-            ds.cache_jsonl = {f"chunk{c}": [json.dumps({"id": f"c{c}_{i}", "title": f"title {i}", "content": "x" * 200}) for i in range(4096)]
-                              for c in range(8)}
-            res = asyncio.run(closed_loop(ds, queries, clients, 3.0))
-            res["batch_window_ms"] = w
-            out["service"].append(res)
-            print(json.dumps(res), file=sys.stderr, flush=True)
-    best = max((r for r in out["service"] if r["clients"] == 256), key=lambda r: r["requests_per_s"])
-    out["best_window_ms_at_256_clients"] = best["batch_window_ms"]
+    for wire in ("json", "objects"):
+        for w in windows:
+            for clients in (1, 32, 256):
+                ds = DataSource(0, "medrag", "pubmed")
+                ds.batch_window_ms = w
+                ds.set_index(idx, LazyMeta(rows))
+                ds.cache_jsonl = {f"chunk{c}": [json.dumps({"id": f"c{c}_{i}", "title": f"title {i}", "content": "x" * 200}) for i in range(4096)]
+                                  for c in range(8)}
+                res = asyncio.run(closed_loop(ds, queries if wire == "json" else arrays, clients, 3.0, wire))
+                res["batch_window_ms"] = w
+                out["service"].append(res)
+                print(json.dumps(res), file=sys.stderr, flush=True)
+    for wire in ("json", "objects"):
+        best = max((r for r in out["service"] if r["clients"] == 256 and r["wire"] == wire), key=lambda r: r["requests_per_s"])
+        out[f"best_window_ms_at_256_clients_{wire}"] = best["batch_window_ms"]
     print(json.dumps(out), flush=True)
 
 
