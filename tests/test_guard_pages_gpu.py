@@ -21,6 +21,7 @@ def _flush_to_end(t, dev):
     """Copy of tensor t whose last byte is the last byte of a fresh device segment."""
     nbytes = t.numel() * t.element_size()
     total = max(12 * (1 << 20), -(-nbytes // SEG) * SEG + SEG) // SEG * SEG   # > 10 MiB: a segment of its own
+    torch.cuda.empty_cache()   # no cached free segment may serve the request: a larger one would be split, with a neighbour behind the buffer
     buf = torch.empty(total, dtype=torch.uint8, device=dev)
     # the guard only guards if the allocation really ends where its device segment ends (another allocator configuration - e.g.
     # expandable segments - could map a neighbour right behind it and the test would pass vacuously)
