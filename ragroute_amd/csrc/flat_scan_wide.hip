@@ -883,7 +883,7 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
     phase = phase + 1 == QB ? 0 : phase + 1;
     if (++kg < KG) continue;
     kg = 0;
-    if (nb > 0) {
+    if (nb > 0 && !(RR_WIDE8_ABL & 128)) {   // (timing-only ablation 128: no epilogue at all - prices what overlapping it could gain)
       asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       static_for<NT>([&](auto ti) {

@@ -127,7 +127,7 @@ class DataSource:
         self.cache_jsonl = {}
         self._parsed_docs = {}
         self._batcher = None
-        self.batch_window_ms = float(os.environ.get("RAGROUTE_BATCH_WINDOW_MS", 2.0))
+        self.batch_window_ms = float(os.environ.get("RAGROUTE_BATCH_WINDOW_MS", 0.2))
 
     # -- loading (data_source.py:69-80) -------------------------------------------------------------
     def load_faiss_index(self):

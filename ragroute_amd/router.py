@@ -187,7 +187,7 @@ class Router:
         self._folded: Optional[FoldedRouter] = None
         self._batcher = None
         self._serve_task = None
-        self.batch_window_ms = float(os.environ.get("RAGROUTE_BATCH_WINDOW_MS", 2.0))
+        self.batch_window_ms = float(os.environ.get("RAGROUTE_BATCH_WINDOW_MS", 0.2))
 
     # -- loading (router.py:106-151) -------------------------------------------------------------
     def load_router(self, model_path=None, scaler_path=None, stats_files=None):
