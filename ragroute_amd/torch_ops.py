@@ -2,7 +2,12 @@
 
     ragroute::flat_topk(xb, xq, k, id_offset=0, l2=False) -> (D f32[nq,k], I i64[nq,k])     index.search, data_source.py:158,186,203
     ragroute::l2_normalize_(x) -> x                                                         faiss.normalize_L2, data_source.py:199
+    ragroute::flat_topk_segments(xb, row_begins, rows, id_offsets, mask_cols, xq, k, route_mask=None) -> (D, I)
+                                                                                            one search over the sources of one encoder
+                                                                                            (config.py:37-71) = their per-source
+                                                                                            index.search + http_server.py:280-293 + rerank.py:3-9
     ragroute::merge_topk(D, I, k, descending=True) -> (D, I)                                rerank.py:3-9, 28-34
+    ragroute::merge_gathered(buf, slots, nq, k_in, k, descending=True) -> (D, I)            the same on the all-gathered exchange buffer, in place
     ragroute::rows_to_half(x, dim, bf16=False, normalize=False) -> Tensor                   ingest / query conversion
     ragroute::router_mlp(xq, folded weights..., b3, prob_threshold) -> (logits, mask)       router.py:241-283, 50-55
 
@@ -67,6 +72,41 @@ def _(xb, xq, k, id_offset=0, l2=False):
     return xq.new_empty((xq.shape[0], k), dtype=torch.float32), xq.new_empty((xq.shape[0], k), dtype=torch.int64)
 
 
+@torch.library.custom_op("ragroute::flat_topk_segments", mutates_args=())
+def flat_topk_segments(xb: torch.Tensor, row_begins: list[int], rows: list[int], id_offsets: list[int], mask_cols: list[int],
+                       xq: torch.Tensor, k: int, route_mask: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+    """rr_flat_search_segments: xb ONE matrix [n, dim] holding source s at rows [row_begins[s], row_begins[s] + rows[s]) (begins
+    multiples of 256); route_mask optional bool/uint8 [nq, C], source s reads column mask_cols[s] (-1: always selected)."""
+    n_seg = len(rows)
+    if not (len(row_begins) == len(id_offsets) == len(mask_cols) == n_seg and 1 <= n_seg <= _lib.RR_MAX_SEGMENTS):
+        raise ValueError("flat_topk_segments: one begin / row count / id offset / mask column per segment (1 .. 32 segments)")
+    if not (xb.is_cuda and xq.is_cuda and xb.dim() == 2 and xq.dim() == 2 and xb.shape[1] == xq.shape[1] and xb.dtype == xq.dtype):
+        raise ValueError("flat_topk_segments: xb [n,dim] and xq [nq,dim] must be CUDA tensors of the same half dtype and padded width")
+    xb, xq = xb.contiguous(), xq.contiguous()
+    nq = xq.shape[0]
+    segs = (_lib.SegmentStruct * n_seg)(*[_lib.SegmentStruct(int(b), int(r), int(o), int(c), 0)
+                                          for b, r, o, c in zip(row_begins, rows, id_offsets, mask_cols)])
+    D = torch.empty((nq, k), dtype=torch.float32, device=xb.device)
+    I = torch.empty((nq, k), dtype=torch.int64, device=xb.device)
+    ws = _workspace(xb.device, k)
+    mptr, mstride = None, 0
+    if route_mask is not None:
+        if route_mask.dtype not in (torch.bool, torch.uint8) or route_mask.dim() != 2 or route_mask.shape[0] != nq or not route_mask.is_cuda:
+            raise ValueError("flat_topk_segments: route_mask must be a bool/uint8 CUDA matrix [nq, C]")
+        route_mask = route_mask.contiguous()
+        mptr, mstride = route_mask.data_ptr(), route_mask.stride(0)
+    with torch.cuda.device(xb.device):
+        check(lib().rr_flat_search_segments(xb.data_ptr(), _dtype_code(xb), xb.shape[0], xb.shape[1], segs, n_seg, xq.data_ptr(), nq, k,
+                                            D.data_ptr(), I.data_ptr(), ws.data_ptr(), ws.numel(), mptr, mstride, _stream()),
+              "rr_flat_search_segments")
+    return D, I
+
+
+@flat_topk_segments.register_fake
+def _(xb, row_begins, rows, id_offsets, mask_cols, xq, k, route_mask=None):
+    return xq.new_empty((xq.shape[0], k), dtype=torch.float32), xq.new_empty((xq.shape[0], k), dtype=torch.int64)
+
+
 @torch.library.custom_op("ragroute::l2_normalize_", mutates_args=("x",))
 def l2_normalize_(x: torch.Tensor) -> None:
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()):
@@ -84,6 +124,18 @@ def merge_topk(D: torch.Tensor, I: torch.Tensor, k: int, descending: bool = True
 @merge_topk.register_fake
 def _(D, I, k, descending=True):
     return D.new_empty((D.shape[0], k), dtype=torch.float32), I.new_empty((I.shape[0], k), dtype=torch.int64)
+
+
+@torch.library.custom_op("ragroute::merge_gathered", mutates_args=())
+def merge_gathered(buf: torch.Tensor, slots: int, nq: int, k_in: int, k: int, descending: bool = True) -> tuple[torch.Tensor, torch.Tensor]:
+    """rr_merge_topk_gathered: buf uint8 [world, bytes per rank] as all_gather_into_tensor leaves the packed candidate buffers."""
+    from .sharded import merge_gathered as _mg
+    return _mg(buf, nq, k_in, slots, k, descending)
+
+
+@merge_gathered.register_fake
+def _(buf, slots, nq, k_in, k, descending=True):
+    return buf.new_empty((nq, k), dtype=torch.float32), buf.new_empty((nq, k), dtype=torch.int64)
 
 
 @torch.library.custom_op("ragroute::rows_to_half", mutates_args=())

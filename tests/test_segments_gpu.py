@@ -204,3 +204,27 @@ def test_config2_exact_size_one_million_rows_bit_exact(gpu):
     D, I = idx.search(xq, 32)
     Dr, Ir = O.flat_search_ip(xb.astype(np.float32), xq, 32)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
+def test_torch_ops_reach_the_segmented_search_and_the_in_place_merge(gpu):
+    """torch.ops.ragroute.flat_topk_segments / merge_gathered are the same entry points as SegmentedIndex / sharded.merge_gathered."""
+    import ragroute_amd.torch_ops  # noqa: F401  (registers the ops)
+    from ragroute_amd import sharded as S
+    rng = np.random.default_rng(31)
+    parts = [int_data(rng, n, 768) for n in (9_000, 100, 30_000)]
+    xq = int_data(rng, 24, 768)
+    mask = rng.integers(0, 2, size=(24, 3)).astype(bool)
+    seg = build(parts, 768, gpu)
+    q = seg.prepare_queries(xq)
+    m = torch.from_numpy(mask).to(gpu)
+    D, I = torch.ops.ragroute.flat_topk_segments(seg._xb, seg.begins, seg.rows, seg.id_offsets, seg.mask_cols, q, 10, m)
+    Dr, Ir = oracle_chain(parts, xq, 10, mask)
+    assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr)
+    buf, Dp, Ip = S.alloc_packed(24, 10, gpu)
+    Dp.copy_(D)
+    Ip.copy_(I)
+    out = torch.stack([buf, buf])
+    D2, I2 = torch.ops.ragroute.merge_gathered(out, 1, 24, 10, 10)
+    from oracle import oracle as O
+    Dw, Iw = O.merge_topk(np.concatenate([Dr, Dr], 1), np.concatenate([Ir, Ir], 1), 10, True)
+    assert np.array_equal(I2.cpu().numpy(), Iw) and np.array_equal(D2.cpu().numpy(), Dw)
