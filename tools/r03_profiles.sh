@@ -14,7 +14,7 @@ echo "bench traced"
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o t --output-format csv -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --sustained-seconds 0 > $O/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o t --output-format csv -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --sustained-seconds 0 > $O/pmc_write.log 2>&1 || exit 1
 F=$(find $O/pmc_fetch -name '*counter_collection.csv' | head -1); W=$(find $O/pmc_write -name '*counter_collection.csv' | head -1)
-python tools/pmc_traffic.py $F $W 15 $O/traffic.json 10000000 768 256 32 fp16 $VER || exit 1
+python tools/pmc_traffic.py $F $W 9 $O/traffic.json 10000000 768 256 32 fp16 $VER || exit 1
 echo "pmc done"
 # 3. other shapes: bench-style lines, three of them also under the kernel trace
 for shape in "1000000 768" "4000000 1024" "2000000 4096" "2000000 2048" "10000000 768 1"; do
