@@ -1,4 +1,5 @@
-"""Seeded random (d, n, nq, k, dtype, metric) cases for the flat search, biased to the kernel-selection boundaries.
+"""Seeded random (d, n, nq, k, dtype, metric) cases for the flat search, biased to the kernel-selection boundaries, and
+(segment_cases / run_segment_case) random segment tables + route masks for the one-pass search over several sources.
 
 Shared by tests/test_fuzz_gpu.py (a bounded set, every GPU run) and tools/fuzz_parity.py (as many as the budget allows)."""
 import numpy as np
@@ -59,6 +60,61 @@ def run_case(c, dev, guard=True):
     D, I = idx.search_prepared(xq_dev, k)
     torch.cuda.synchronize()
     Dr, Ir = (O.flat_search_l2 if c["metric"] == "l2" else O.flat_search_ip)(xb, xq, k)
+    ok = np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr)
+    del keep_b, keep_q
+    return ok
+
+
+SEG_ROWS = [0, 1, 31, 33, 255, 256, 257, 1000, 3633, 8192, 8674, 20_011, 57_638, 126_000, 301_000]   # FeB4RAG / MedRAG small-source sizes among them
+
+
+def segment_cases(seed, count, max_work=8e9):
+    """Random segment tables for rr_flat_search_segments: 1 ... 7 sources of assorted sizes (empty and one-row sources, totals
+    below and above the 8192-row dense path, several chunks), every width class, batch sizes around the query-block boundaries,
+    mask densities from 'everything' to 'almost nothing' (a query routed to one tiny source is the hard case for the schedule)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < count:
+        d = int(rng.choice([64, 384, 768, 769, 1024, 1536, 2048, 4096]))
+        n_seg = int(rng.integers(1, 8))
+        rows = [int(rng.choice(SEG_ROWS)) + int(rng.integers(0, 2)) for _ in range(n_seg)]
+        nq = int(rng.choice(QUERIES))
+        k = int(rng.choice([1, 10, 32, 100]))
+        if sum(rows) * d * nq > max_work or sum(rows) * d > 1.2e9:
+            continue
+        out.append({"d": d, "rows": rows, "nq": nq, "k": k, "dtype": "fp16" if rng.integers(0, 2) else "bf16",
+                    "density": float(rng.choice([1.0, 0.9, 0.5, 0.15])), "seed": int(rng.integers(0, 2 ** 31))})
+    return out
+
+
+def run_segment_case(c, dev):
+    """One segmented case on integer data against the oracle chain (per-source oracle top-k -> concat -> oracle merge), the matrix
+    flush against the end of its device segment, gaps poisoned."""
+    import torch
+    from ragroute_amd.flat_index import SegmentedIndex
+    from tests.test_guard_pages_gpu import _flush_to_end
+    from tests.test_segments_gpu import oracle_chain
+    from tests.util import int_data
+    rng = np.random.default_rng(c["seed"])
+    d, rows, nq, k = c["d"], c["rows"], c["nq"], c["k"]
+    parts = [int_data(rng, n, d) for n in rows]
+    xq = int_data(rng, nq, d)
+    mask = rng.random((nq, len(rows))) < c["density"]
+    seg = SegmentedIndex(d, rows, dtype=c["dtype"], device=dev)
+    tdt = torch.float16 if c["dtype"] == "fp16" else torch.bfloat16
+    host = torch.full((max(1, seg.n_rows_total), seg.dim), float("nan"), dtype=tdt)
+    host[::5] = 30000.0
+    for s_, p in enumerate(parts):
+        host[seg.begins[s_]: seg.begins[s_] + rows[s_]] = 0
+        host[seg.begins[s_]: seg.begins[s_] + rows[s_], :d] = torch.from_numpy(p).to(tdt)
+    keep_b, arena = _flush_to_end(host, dev)
+    seg._xb = arena
+    xq_h = torch.zeros((nq, seg.dim), dtype=tdt)
+    xq_h[:, :d] = torch.from_numpy(xq).to(tdt)
+    keep_q, xq_dev = _flush_to_end(xq_h, dev)
+    D, I = seg.search_prepared(xq_dev, k, route_mask=torch.from_numpy(mask.astype(np.uint8)).to(dev))
+    torch.cuda.synchronize()
+    Dr, Ir = oracle_chain(parts, xq, k, mask)
     ok = np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr)
     del keep_b, keep_q
     return ok

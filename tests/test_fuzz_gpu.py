@@ -10,11 +10,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _fuzz_in_child(args):
+def _fuzz_in_child(args, gen="cases", run="run_case"):
     """The cases run on the guard-page layout, where an over-read is a GPU fault that kills the process: a child process turns
     that into ONE failed test (with the case it died on in the output) instead of an aborted suite."""
-    code = ("import torch\nfrom tests.fuzz_cases import cases, run_case\n"
-            f"failed = []\nfor c in cases({args}):\n    print('case', c, flush=True)\n    if not run_case(c, torch.device('cuda:0')): failed.append(c)\n"
+    code = (f"import torch\nfrom tests.fuzz_cases import {gen}, {run}\n"
+            f"failed = []\nfor c in {gen}({args}):\n    print('case', c, flush=True)\n    if not {run}(c, torch.device('cuda:0')): failed.append(c)\n"
             "print('failed', failed)\nassert not failed\nprint('ok')")
     env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1200)
@@ -28,3 +28,10 @@ def test_seeded_fuzz_sample(gpu):
 def test_seeded_fuzz_sample_large_corpora(gpu):
     """The same on 70 K ... 2 M-row corpora: bootstrap sample, 2 ... 4 chunk launches and their compactions at every width class."""
     _fuzz_in_child("20261005, 16, max_work=3e10, big=True")
+
+
+
+def test_seeded_fuzz_segmented_search(gpu):
+    """Random segment tables, widths, batch sizes and route masks for the one-pass search over several sources, bit-exact against
+    the oracle chain on the guard-page layout."""
+    _fuzz_in_child("20261006, 60", "segment_cases", "run_segment_case")
