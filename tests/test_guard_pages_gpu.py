@@ -1,8 +1,9 @@
 """GPU: no kernel may read past the end of the corpus or of the query block.
 
-Both tensors are placed flush against the END of a dedicated device allocation (a multiple of 2 MiB, which PyTorch's
-caching allocator requests from the driver as one segment of exactly that size), so a read beyond the last byte leaves
-the mapping and faults instead of silently reading a neighbour.  Results are also checked against the oracle."""
+Both tensors are placed flush against the END of a mapping made with HIP's virtual-memory API whose address range is one granule
+longer than the mapping (tests/guard_alloc.py), so a read beyond the last byte hits unmapped addresses and faults instead of
+silently reading a neighbour.  (Rounds 1-2 relied on PyTorch's caching allocator handing out exact-size segments; asserting the
+segment end in round 3 showed it often did not.)  Results are also checked against the oracle; the cases run in child processes."""
 import os
 import subprocess
 import sys
@@ -14,22 +15,19 @@ import torch
 from tests.util import int_data
 
 pytestmark = pytest.mark.gpu
-SEG = 2 << 20
 
 
 def _flush_to_end(t, dev):
-    """Copy of tensor t whose last byte is the last byte of a fresh device segment."""
-    nbytes = t.numel() * t.element_size()
-    total = max(12 * (1 << 20), -(-nbytes // SEG) * SEG + SEG) // SEG * SEG   # > 10 MiB: a segment of its own
-    torch.cuda.empty_cache()   # no cached free segment may serve the request: a larger one would be split, with a neighbour behind the buffer
-    buf = torch.empty(total, dtype=torch.uint8, device=dev)
-    # the guard only guards if the allocation really ends where its device segment ends (another allocator configuration - e.g.
-    # expandable segments - could map a neighbour right behind it and the test would pass vacuously)
-    segs = [sg for sg in torch.cuda.memory_snapshot() if sg["address"] <= buf.data_ptr() < sg["address"] + sg["total_size"]]
-    assert len(segs) == 1 and segs[0]["address"] + segs[0]["total_size"] == buf.data_ptr() + total, "guard layout: the buffer does not end its segment"
-    view = buf[total - nbytes:].view(t.dtype).view(t.shape)
-    view.copy_(t)
-    return buf, view
+    """Copy of tensor t whose last byte is the last MAPPED byte of its address range (tests/guard_alloc.py: HIP virtual-memory
+    reservation one granule longer than the mapping), so a read past it faults whatever the caching allocator's state.  Returns
+    (owner, view): keep `owner` alive as long as the view is used."""
+    from tests.guard_alloc import GuardedBuffer
+    nbytes = max(1, t.numel() * t.element_size())
+    owner = GuardedBuffer(nbytes, dev.index or 0)
+    view = owner.tensor(tuple(t.shape), t.dtype) if t.numel() else torch.empty(t.shape, dtype=t.dtype, device=dev)
+    if t.numel():
+        view.copy_(t)
+    return owner, view
 
 
 def _run_cases(dev, cases):
