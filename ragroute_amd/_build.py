@@ -178,3 +178,21 @@ def build(force=False, verbose=False):
         check_isa(os.path.join(OBJ_DIR, "flat_scan_wide" + suffix + ".o"))
     _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + [o for _, o, _ in jobs], "hipcc -shared")
     return lib_path
+
+
+def build_asan_host(out_dir=None):
+    """an AddressSanitizer build of the binding's HOST code (capi.hip: argument validation, workspace carving, the
+    chunk / segment schedules) linked with the ordinary kernel objects - for the CPU argument-validation tests only (no GPU ASan
+    on this pool).  Returns (library path, path of the ASan runtime to LD_PRELOAD)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    build()                                                   # the ordinary objects
+    out_dir = out_dir or OBJ_DIR
+    obj = os.path.join(out_dir, "capi_asan.o")
+    lib_path = os.path.join(out_dir, "libragroute_hip_asan.so")
+    _run([hipcc] + PRODUCT_FLAGS + ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan",
+                                    "-c", os.path.join(CSRC, "capi.hip"), "-o", obj], "hipcc -fsanitize=address -c capi.hip")
+    others = [os.path.join(OBJ_DIR, s.replace(".hip", ".o")) for s in SOURCES if s != "capi.hip"]
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address", "-shared-libsan", "-o", lib_path, obj] + others,
+         "hipcc -shared (asan)")
+    rt = _run([os.path.join(LLVM_BIN, "clang"), "-print-file-name=libclang_rt.asan-x86_64.so"], "clang -print-file-name").stdout.strip()
+    return lib_path, rt
