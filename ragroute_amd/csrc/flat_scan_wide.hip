@@ -684,7 +684,7 @@ __device__ __forceinline__ f32x4 read_acc_fixed128() {
 #define RR_WIDE8_SPREAD 0
 #endif
 #ifndef RR_WIDE8_ABL
-#define RR_WIDE8_ABL 0   // development, timing only (wrong results): 8 = every second LDS fragment read skipped, 32 = every query load
+#define RR_WIDE8_ABL 0   // development, timing only (wrong results): 8 = every second LDS fragment read skipped, 256 = 8 extra reads, 32 = every query load
 #endif                   // issued twice, 64 = nothing (baseline with the insertion path shut, as the others have it)
 #if RR_WIDE8_ABL && !defined(RR_DEV_VARIANTS)
 #error "RR_WIDE8_ABL removes work from the step (wrong scores, timing only): RR_DEV_VARIANTS builds only"
@@ -857,6 +857,9 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
           constexpr int fn = f + NB;
           lds_read_frag(c[f % NB], ((fn >> 1) & 1) ? ab1 : ab0, (fn >> 2) * 4096 + (fn & 1) * 2048);
         }
+        // (timing-only ablation 256, with 8: eight extra LDS fragment reads per step into the ring slots 8 leaves unused - together the
+        // LDS load of a row-split layout that reads its query fragments from LDS: 16 A + 8 B reads per wave and step instead of 32)
+        if constexpr ((RR_WIDE8_ABL & 256) != 0 && (f & 3) == 1) lds_read_frag(c[f % NB], ab0, (f >> 2) * 4096);
 #if RR_WIDE8_SPREAD
         if constexpr ((f & 3) == 1 && f < 16 && (f >> 3) < NQB) query_load_into(q[PN][f >> 3][(f >> 2) & 1], qoff[f >> 3], qsb, ((f >> 2) & 1) * RR_WIDE_QPAR);
         if constexpr ((f & 3) == 1 && f >= 16) issue_piece(dkg, dslot, (f - 16) >> 2);
