@@ -56,6 +56,8 @@ CASES = [
     (1024, [30_000, 3_633, 8_674, 25_000], 256, 10),     # ... 256 queries: 8-wave wide-row kernel
     (4096, [9_000, 2_000, 14_000], 256, 10),             # wide rows: 4-wave kernel, K rotation per 256-row group
     (128, [50_000, 50_000], 37, 100),
+    (768, [20_000, 5_000, 9_000], 8, 300),               # k beyond one candidate-buffer generation
+    (256, [700 + 13 * i for i in range(32)], 40, 10),   # RR_MAX_SEGMENTS sources
 ]
 
 
