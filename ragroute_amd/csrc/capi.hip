@@ -109,6 +109,7 @@ struct Workspace {
 Workspace carve(char* base, int k, int grid) {
   using namespace rr;
   const int cap = cand_cap_for_k(k);
+  const int bpw = k <= 128 ? 8 : 4;   // candidate buffers per (workgroup, query): the row-split wide-row kernel (k <= 128) uses 8
   Workspace w;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return base ? base + o : (char*)nullptr; };
@@ -121,10 +122,10 @@ Workspace carve(char* base, int k, int grid) {
   w.ranges = (RangeEntry*)take((size_t)kMaxChunks * kMaxSegments * sizeof(RangeEntry));
   w.list_cnt = (uint32_t*)take(kQueriesPerBlock * sizeof(uint32_t));
   w.list = (uint64_t*)take((size_t)kQueriesPerBlock * kMaxK * sizeof(uint64_t));
-  w.cand_cnt = (uint32_t*)take((size_t)kQueriesPerBlock * grid * 4 * sizeof(uint32_t));
+  w.cand_cnt = (uint32_t*)take((size_t)kQueriesPerBlock * grid * bpw * sizeof(uint32_t));
   w.scratch = (uint64_t*)take((size_t)grid * 8 * cap * sizeof(uint64_t));  // up to 2 workgroups per CU x 4 waves
   w.dense = (float*)take((size_t)kQueriesPerBlock * kSampleRows * sizeof(float));
-  w.cand = (uint64_t*)take((size_t)kQueriesPerBlock * grid * 4 * cap * sizeof(uint64_t));
+  w.cand = (uint64_t*)take((size_t)kQueriesPerBlock * grid * bpw * cap * sizeof(uint64_t));
   w.xqs = take((size_t)kQueriesPerBlock * kMaxDim * 2);  // the query block in MFMA-fragment order (prep kernel): 256 queries x the padded dim
   w.total = off;
   return w;
@@ -234,7 +235,7 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
     memset(&s, 0, sizeof(s));
     s.thr = w.thr; s.list = w.list; s.list_cnt = w.list_cnt; s.cand = w.cand; s.cand_cnt = w.cand_cnt;
     s.dense = w.dense; s.dense_ld = kSampleRows; s.n_rows = (uint32_t)n_rows; s.nq = (uint32_t)nqb;
-    s.nbuf = (uint32_t)grid * (uint32_t)(dtype == kDtypeI8 ? 4 : scan_bufs_per_wg(dim, half_sqnorm != nullptr)); s.list_ld = kMaxK; s.cap = cap; s.k = k;
+    s.nbuf = (uint32_t)grid * (uint32_t)(dtype == kDtypeI8 ? 4 : scan_bufs_per_wg(dim, nqb, half_sqnorm != nullptr, k)); s.list_ld = kMaxK; s.cap = cap; s.k = k;
     if (segs) s.seg = SegTables{w.seg_tile_end, w.seg_row_limit, w.seg_row_begin, w.seg_id_offset, w.seg_sel, segs->n};
     ScanArgs a;
     memset(&a, 0, sizeof(a));

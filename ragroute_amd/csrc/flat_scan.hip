@@ -538,15 +538,15 @@ int scan_query_blocks_per_wave(int D, int nq, bool l2) {
   return RR_WIDE_QFRAG ? 4 : 0;   // wide-row kernels: the 16 blocks of a 256-query pass, same [block][k slice][lane][8] order
 }
 
-// candidate buffers per (workgroup, query) of the kernel that will serve this dim: the production kernels all use 4 lane quarters
-int scan_bufs_per_wg(int D, bool l2) {
+// candidate buffers per (workgroup, query) of the kernel that will serve this block: 4 lane quarters; the row-split wide-row
+// kernel 8 (two waves share each query)
+int scan_bufs_per_wg(int D, int nq, bool l2, int k) {
   read_variant_env();
 #ifdef RR_DEV_VARIANTS
-  return l2 ? 4 : dev_scan_bufs_per_wg(D, g_scan_variant, g_generic_tall);  // (the development kernels have no L2 form)
-#else
-  (void)D; (void)l2;
-  return 4;
+  if (!l2 && dev_scan_bufs_per_wg(D, g_scan_variant, g_generic_tall) != 4) return dev_scan_bufs_per_wg(D, g_scan_variant, g_generic_tall);
 #endif
+  if (half_resident_dim(D) && nq < g_wide_min_queries && !l2) return 4;
+  return scan_wide_rowsplit(D, nq, l2, k) ? 8 : 4;
 }
 
 template <typename T, int D, bool DENSE, bool NT = false, bool L2 = false>

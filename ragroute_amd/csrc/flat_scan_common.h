@@ -335,13 +335,17 @@ __device__ __forceinline__ float max4v(const f32x4& v) { return max4(v[0], v[1],
 // INLINE_COMPACT: no function call in the slow path (for kernels that keep asynchronously loaded registers live across it)
 // QPW: queries per wave (the wave's queries are wave * QPW + qb * 16 + col); WAVES: waves per workgroup (compaction scratch slots);
 // DEAL: the query blocks are dealt round robin instead (slot qb of wave w = block 4 qb + w: flat_scan16_kernel)
+// qwave: the wave index the lane's QUERIES are derived from, where that is not the wave itself (row-split kernel: two waves share a
+// query quarter; `wave` still names the wave's own compaction scratch)
 template <bool DENSE, int NQB, int QPW = 64, bool INLINE_COMPACT = false, int WAVES = 256 / QPW, bool DEAL = false>
-__device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& st, f32x4 (&acc)[2][4], uint32_t j, int lane, int wave) {
+__device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& st, f32x4 (&acc)[2][4], uint32_t j, int lane, int wave,
+                                                int qwave = -1) {
   const int col = lane & 15, g = lane >> 4;
+  const int qw = qwave < 0 ? wave : qwave;
   if (DENSE) {
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
-      float* d = a.dense + (size_t)(DEAL ? (qb * 4 + wave) * 16 + col : wave * QPW + qb * 16 + col) * a.dense_ld + j * kTileRows + 4 * g;
+      float* d = a.dense + (size_t)(DEAL ? (qb * 4 + qw) * 16 + col : qw * QPW + qb * 16 + col) * a.dense_ld + j * kTileRows + 4 * g;
       *(f32x4*)d = acc[0][qb];
       *(f32x4*)(d + 16) = acc[1][qb];
     }
@@ -353,7 +357,7 @@ __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& s
     st.row_limit = e.row_limit;
     uint32_t qi[4];
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) qi[qb] = DEAL ? (qb * 4 + wave) * 16 + col : wave * QPW + (qb < NQB ? qb : 0) * 16 + col;
+    for (int qb = 0; qb < 4; ++qb) qi[qb] = DEAL ? (qb * 4 + qw) * 16 + col : qw * QPW + (qb < NQB ? qb : 0) * 16 + col;
     load_thresholds<NQB>(a, e.seg, qi, st.thr);
   }
   const uint32_t tile = a.tile_first + j * a.tile_stride + (uint32_t)st.cur.delta;
@@ -445,6 +449,7 @@ constexpr size_t kNtThresholdBytes = 256ull << 20;
 #endif                    // instruction) instead of 16 rows x 64 B of the row-major block; 0 = row-major (A/B builds)
 hipError_t launch_scan_wide(const ScanArgs& a, int dtype, int D, bool dense, int grid, hipStream_t st);
 const char* scan_wide_kernel_name(int D, int nq);
+bool scan_wide_rowsplit(int D, int nq, bool l2, int k);   // the row-split kernel serves this launch (8 candidate buffers per workgroup and query)
 
 // flat_scan_dev.hip (only in builds with -DRR_DEV_VARIANTS): the development kernels behind RR_SCAN_VARIANT / RR_GENERIC_TALL
 bool dev_scan_handles(const ScanArgs& a, int D, int variant, int tall);

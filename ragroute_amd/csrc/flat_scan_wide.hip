@@ -932,6 +932,206 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
   for (int qb = 0; qb < NQB; ++qb) a.cand_cnt[(wave * QPW + qb * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
 }
 
+// ---- row-split 8-wave kernel (round 3): 209 ... 256 queries at 768 < d <= 2048 -------------------------------------------------
+// The 8-wave kernel above is LDS-bound: each wave multiplies 256 rows x 32 queries, so every A fragment feeds two MFMAs and the CU
+// reads 256 KB of LDS per K step (2048 LDS cycles against 2048 MFMA cycles).  Here the eight waves are 2 row halves x 4 query
+// quarters - a wave multiplies 128 rows x 64 queries, an A fragment feeds FOUR MFMAs - and the queries of a K step are DMA'd into
+// LDS once per CU (a second slab next to the corpus slab: same 8-rows-x-128-bytes pieces, same source-side swizzle, the wave
+// reads its 8 query fragments from there at the start of the step).  Per step and CU: 64 KB through the vector-memory path as
+// before, 128 KB (A) + 64 KB (B) of LDS reads instead of 256 KB, no query registers in flight (no prefetch-register hazards).
+// Timing-only ablations priced it at +5 ... 7 % (profiles/r03/wide8_rowsplit_pricing.json).  Rings: corpus 3 slots (two steps ahead:
+// HBM latency), queries 2 slots (one step ahead: they come from L2) = all 160 KB of LDS.  Two waves share each query, so a
+// workgroup owns 8 candidate buffers per query (row half x lane quarter).
+template <typename T>
+__global__ __launch_bounds__(512) void flat_scan_wide_rs_kernel(const ScanArgs a, const int D) {
+  typedef typename Mfma<T>::frag frag;
+  constexpr int NT = 8;                    // 32-row tiles per group (256 rows)
+  constexpr int SLAB = NT * 4096;          // one K step of 256 rows (or of the 256 queries) in LDS
+  constexpr int NSC = 3, NSQ = 2;          // corpus / query ring slots
+  constexpr int QBASE = NSC * SLAB;
+  constexpr int NF = 16;                   // A fragments per wave and step: (k slice, tile of the wave's row half, row block)
+  constexpr int NB = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..7
+  const int rh = wave & 1, qq = wave >> 1;                             // row half (tiles 4 rh .. +3), query quarter (queries 64 qq .. +63)
+  const int col = lane & 15, g = lane >> 4;
+  const int KG = D / 64;
+  const uint32_t n_tiles = a.n_tiles;
+  const uint32_t n_groups = (n_tiles + NT - 1) / NT;
+
+  uint32_t roff[2];
+  {
+    const int rho = col & 7, p = col >> 3;
+    const int f = ((rho >> 1) & 3) | (p << 2);
+#pragma unroll
+    for (int par = 0; par < 2; ++par) roff[par] = p * 1024 + rho * 128 + (((4 * par + g) ^ f) * 16);
+  }
+  // DMA side, both slabs: wave w fills row octet o = w & 3 (rows / queries 8 o .. +7) of tiles 4 (w >> 2) .. +3
+  const int oct = wave & 3, tbase = (wave >> 2) * 4;
+  const int rho_w = lane >> 3, sig = lane & 7;
+  const int f_w = ((rho_w >> 1) & 3) | ((oct & 1) << 2);
+  const int c_w = sig ^ f_w;
+  const size_t row_bytes = (size_t)D * 2;
+  const char* dbase = (const char*)a.xb;
+  uint32_t voff[4], qvoff[4];
+  int drot = 0;
+  TileCursor dcur;
+  cursor_init(a, dcur);
+  auto dma_new_group = [&](uint32_t grp) {
+    if (grp >= n_groups) return;
+    const uint32_t tile0 = cursor_tile(a, dcur, grp * NT);
+    const uint32_t row_base = tile0 * kTileRows;
+    dbase = (const char*)a.xb + (size_t)row_base * row_bytes;
+    drot = wide_rotation_of_tile(tile0, KG);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t j = grp * NT + tbase + i;
+      j = j < n_tiles ? j : n_tiles - 1;
+      uint32_t row = (a.tile_first + j * a.tile_stride + (uint32_t)dcur.delta) * kTileRows + oct * 8 + rho_w;
+      row = row < a.n_rows ? row : a.n_rows - 1;
+      voff[i] = (row - row_base) * (uint32_t)row_bytes + c_w * 16;
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t qrow = (uint32_t)((tbase + i) * 32 + oct * 8 + rho_w);
+    qrow = qrow < a.nq ? qrow : a.nq - 1;              // slots past nq repeat the last query (their thresholds are +inf)
+    qvoff[i] = qrow * (uint32_t)row_bytes + c_w * 16;  // < 256 x 16 KB
+  }
+  auto issue_cpiece = [&](int kg, int slot, int i) {
+    const char* sb = dbase + (size_t)wide_rotated(kg, drot, KG) * 128;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + voff[i]),
+                                     (__attribute__((address_space(3))) void*)(smem + slot * SLAB + (tbase + i) * 4096 + oct * 1024), 16, 0, 2);
+  };
+  auto issue_qpiece = [&](int kcol, int slot, int i) {   // kcol: the (rotated) 64-wide column group; default cache policy: every group re-reads it
+    const char* sb = (const char*)a.xq + (size_t)kcol * 128;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + qvoff[i]),
+                                     (__attribute__((address_space(3))) void*)(smem + QBASE + slot * SLAB + (tbase + i) * 4096 + oct * 1024), 16, 0, 0);
+  };
+
+  LaneState4 st;
+  lane_state_segments_init(a, st);
+  const uint32_t nbuf = gridDim.x * 8;
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) {
+    const uint32_t qi = qq * 64 + qb * 16 + col;
+    st.thr[qb] = a.thr[qi];
+    st.cnt[qb] = 0;
+    st.off[qb] = (qi * nbuf + blockIdx.x * 8 + rh * 4 + g) * (uint32_t)a.cap;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(st.thr[0]), "+v"(st.thr[1]), "+v"(st.thr[2]), "+v"(st.thr[3]));
+
+  uint32_t grp = blockIdx.x, dgrp = blockIdx.x;
+  int dkg = 0, dslot = 0;
+  int rot = wide_group_rotation(a, grp, NT, KG), rot_next = wide_group_rotation(a, grp + gridDim.x, NT, KG);   // query side
+  auto dma_advance = [&]() {
+    if (++dkg == KG) { dkg = 0; dgrp += gridDim.x; dma_new_group(dgrp); }
+    if (++dslot == NSC) dslot = 0;
+  };
+  // queue discipline (in-order vmcnt): per step a wave issues the 4 query pieces of step s+1 FIRST, then the 4 corpus pieces of
+  // step s+2; "all but the 4 youngest have landed" at the end of step s therefore means: queries s+1 and corpus s+1 are in LDS
+  auto closing_wait = [&]() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); };
+  if (grp < n_groups) {
+    dma_new_group(dgrp);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_cpiece(dkg, dslot, i);          // corpus step 0
+    dma_advance();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_qpiece(wide_rotated(0, rot, KG), 0, i);   // queries step 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_cpiece(dkg, dslot, i);          // corpus step 1
+    dma_advance();
+    closing_wait();
+  }
+
+  int cslot = 0, qslot = 0, kg = 0;
+  // accumulator of (tile t of the row half, row block rb, query block qb): a[4 ((2 t + rb) 4 + qb) ..+3]
+  auto step = [&](auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    __builtin_amdgcn_s_barrier();
+    const int nkcol = kg + 1 >= KG ? wide_rotated(0, rot_next, KG) : wide_rotated(kg + 1, rot, KG);
+    // (the wave's part of each slab - its query quarter = 2 "tiles" of 32 queries, its row half = 4 tiles - goes into the address
+    // register, the rest is the instruction's immediate offset)
+    uint32_t qa[2], ca[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      qa[par] = (uint32_t)(QBASE + qslot * SLAB + qq * 8192) + roff[par];
+      ca[par] = (uint32_t)(cslot * SLAB + rh * 16384) + roff[par];
+    }
+    frag bq[2][4];            // B fragments of the step: [k slice][query block of the wave]
+    frag c[NB];               // A fragment f lives in c[f % 8]; f: k slice par = f >> 3, tile t = (f >> 1) & 3 of the row half, row block rb = f & 1
+    auto read_a = [&](auto fi) {
+      constexpr int f = decltype(fi)::value;
+      lds_read_frag(c[f % NB], ca[f >> 3], ((f >> 1) & 3) * 4096 + (f & 1) * 2048);
+    };
+    auto read_b = [&](auto pi, auto qi) {
+      constexpr int par = decltype(pi)::value, qb = decltype(qi)::value;
+      lds_read_frag(bq[par][qb], qa[par], (qb >> 1) * 4096 + (qb & 1) * 2048);
+    };
+    // Read schedule (LDS reads of a wave return in order, lgkmcnt(N) = all but the N youngest have landed).  The step starts right
+    // after a barrier with EVERY wave of the CU reading, so the first MFMA must depend on as few reads as possible:
+    //   issue order   A0 B00 B01 B02 B03 A1 A2 A3 | after f=0: B10 A4 | f=1: B11 A5 | f=2: B12 A6 | f=3: B13 A7 | f=k (4..11): A(k+4)
+    // (first version: all 8 B fragments + 8 A fragments up front - 72 reads CU-wide ahead of every wave's first MFMA, no gain over
+    // the 8-wave kernel)
+    // the query pieces of step s+1 go out first: they have only this one step to land (L2 latency), the corpus pieces two
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_qpiece(nkcol, qslot ^ 1, i);
+    read_a(std::integral_constant<int, 0>{});
+    static_for<4>([&](auto qi) { read_b(std::integral_constant<int, 0>{}, qi); });
+    read_a(std::integral_constant<int, 1>{});
+    read_a(std::integral_constant<int, 2>{});
+    read_a(std::integral_constant<int, 3>{});
+    static_for<NF>([&](auto fi) {
+      constexpr int f = decltype(fi)::value;
+      constexpr int par = f >> 3, t = (f >> 1) & 3, rb = f & 1;
+      // reads issued before this fragment's MFMAs, and the issue index of A[f]
+      constexpr int issued = f == 0 ? 8 : f < 4 ? 8 + 2 * f : f < 12 ? 12 + f : 24;
+      constexpr int idx_a = f == 0 ? 0 : f < 4 ? 4 + f : f < 8 ? 2 * f + 1 : 8 + f;
+      static_for<4>([&](auto qi) {
+        constexpr int qb = decltype(qi)::value;
+        if constexpr (f == 0) lgkm_wait<issued - 1 - (1 + qb)>();     // B0[qb] is read 1 + qb
+        else if constexpr (qb == 0) lgkm_wait<issued - 1 - idx_a>();   // (every B fragment this k slice needs was issued before A[f])
+        Mfma16Fixed128<T>::template run<4 * ((2 * t + rb) * 4 + qb), FIRST && par == 0>(c[f % NB], bq[par][qb]);
+      });
+      if constexpr (f < 4) read_b(std::integral_constant<int, 1>{}, std::integral_constant<int, f>{});
+      if constexpr (f + 4 < NF) read_a(std::integral_constant<int, f + 4>{});
+      if constexpr ((f & 3) == 1) issue_cpiece(dkg, dslot, f >> 2);       // corpus of step s+2, spread over the MFMA stream
+    });
+    dma_advance();
+    if (++cslot == NSC) cslot = 0;
+    qslot ^= 1;
+    closing_wait();
+  };
+  while (grp < n_groups) {
+    if (kg == 0) step(std::true_type{});
+    else step(std::false_type{});
+    if (++kg < KG) continue;
+    kg = 0;
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<4>([&](auto ti) {
+      constexpr int t = decltype(ti)::value;
+      const uint32_t j = grp * NT + 4 * rh + t;
+      if (j < n_tiles) {
+        f32x4 e[2][4];
+        static_for<4>([&](auto qi) {
+          constexpr int qb = decltype(qi)::value;
+          e[0][qb] = read_acc_fixed128<4 * ((2 * t) * 4 + qb)>();
+          e[1][qb] = read_acc_fixed128<4 * ((2 * t + 1) * 4 + qb)>();
+        });
+        tile_epilogue16<false, 4, 64, true, 8>(a, st, e, j, lane, wave, qq);
+      }
+    });
+    grp += gridDim.x;
+    rot = rot_next;
+    rot_next = wide_group_rotation(a, grp + gridDim.x, NT, KG);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) a.cand_cnt[(qq * 64 + qb * 16 + col) * nbuf + blockIdx.x * 8 + rh * 4 + g] = st.cnt[qb];
+}
+
 static int wide_pd() {  // RR_WIDE_PD: 0 = the round-1 kernel (one slab in flight), 2 / 3 = query prefetch distance of the deeper pipeline
   static const int v = [] {
     const char* e = getenv("RR_WIDE_PD");
@@ -962,8 +1162,14 @@ static int wide_waves_for(int D, int nq) {
   return (nblk == 9 || nblk == 11 || nblk == 12) ? 4 : 8;
 }
 
+// 209 ... 256 queries at 768 < d <= 2048, inner product, k <= 128: the row-split kernel (RR_WIDE_RS=0 / RR_WIDE_WAVES switch it off)
+bool scan_wide_rowsplit(int D, int nq, bool l2, int k) {
+  static const bool on = [] { const char* e = getenv("RR_WIDE_RS"); return !(e && atoi(e) == 0) && !getenv("RR_WIDE_WAVES"); }();
+  return on && wide_pd() != 0 && !l2 && D > kMaxResidentDim && D <= 2048 && nq > 208 && k <= 128;
+}
 // name of the filter-launch kernel launch_scan_wide_t picks (reported by rr_flat_scan_kernel_name)
 const char* scan_wide_kernel_name(int D, int nq) {
+  if (scan_wide_rowsplit(D, nq, false, 32)) return "flat_scan_wide_rs_kernel";
   if (wide_pd() == 0) return "flat_scan_wide_kernel";
   return wide_waves_for(D, nq) == 8 ? "flat_scan_wide8_kernel" : "flat_scan_wide_pd_kernel";
 }
@@ -996,6 +1202,13 @@ static hipError_t launch_scan_wide_t(const ScanArgs& a, int D, bool dense, int g
   {                                                                                       \
     RR_PD3_CASE(DENSE_, L2_, NQB_)                                                        \
     RR_LAUNCH_KERNEL(flat_scan_wide_pd_kernel<T, DENSE_, L2_, NQB_, 2>)                   \
+  }
+  if (!dense && scan_wide_rowsplit(D, (int)a.nq, l2, a.k)) {
+    const size_t lds_rs = (size_t)5 * 8 * 4096;   // 3 corpus + 2 query slots of 32 KB: all 160 KB
+    hipError_t ers = hipFuncSetAttribute((const void*)flat_scan_wide_rs_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs);
+    if (ers != hipSuccess) return ers;
+    hipLaunchKernelGGL((flat_scan_wide_rs_kernel<T>), dim3(grid), dim3(512), lds_rs, st, a, D);
+    return hipGetLastError();
   }
   if (!dense && pd != 0 && wide_waves_for(D, (int)a.nq) == 8) {
     hipError_t e8;

@@ -50,7 +50,7 @@ struct ScanArgs {
 hipError_t launch_flat_scan(const ScanArgs& a, int dtype, int D, bool dense, int grid, hipStream_t st);
 int scan_padded_dim(int d);
 const char* scan_kernel_name(int D, int nq, bool l2);  // filter-launch kernel for a block of nq queries
-int scan_bufs_per_wg(int D, bool l2);
+int scan_bufs_per_wg(int D, int nq, bool l2, int k);   // candidate buffers per (workgroup, query) of the kernel that will serve the block
 int scan_queries_per_launch(int D, int nq);  // nq = queries of the whole call
 int scan_query_blocks_per_wave(int D, int nq, bool l2);  // 4 / 2: the kernel reads the fragment-order copy; 0: row-major queries
 

@@ -237,17 +237,23 @@ __global__ __launch_bounds__(1024) void compact_kernel(SelectArgs a, FinalizeArg
   };
   // fast path: every buffer of this query fits next to the running list (the common case: a few hundred survivors)
   bool done = false;
-  if (a.nbuf <= 1024) {
-    int c = 0;
+  if (a.nbuf <= 2048) {   // (one buffer per thread; two where a workgroup owns 8 buffers per query: the row-split wide-row kernel)
+    int c0 = 0, c1 = 0;
     if ((uint32_t)tid < a.nbuf) {
-      c = (int)a.cand_cnt[q * a.nbuf + tid];
-      if (c > cap) c = cap;
+      c0 = (int)a.cand_cnt[q * a.nbuf + tid];
+      if (c0 > cap) c0 = cap;
+    }
+    if ((uint32_t)tid + 1024u < a.nbuf) {
+      c1 = (int)a.cand_cnt[q * a.nbuf + tid + 1024];
+      if (c1 > cap) c1 = cap;
     }
     int offs;
-    const int tot = block_scan(c, offs);
+    const int tot = block_scan(c0 + c1, offs);
     if (fill + tot <= kSelectCap) {
       const uint64_t* src = a.cand + ((size_t)q * a.nbuf + tid) * cap;
-      for (int e = 0; e < c; ++e) keys[fill + offs + e] = src[e];
+      for (int e = 0; e < c0; ++e) keys[fill + offs + e] = src[e];
+      src += (size_t)1024 * cap;
+      for (int e = 0; e < c1; ++e) keys[fill + offs + c0 + e] = src[e];
       fill += tot;
       __syncthreads();
       done = true;
