@@ -932,7 +932,7 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
   for (int qb = 0; qb < NQB; ++qb) a.cand_cnt[(wave * QPW + qb * 16 + col) * nbuf + blockIdx.x * 4 + g] = st.cnt[qb];
 }
 
-// ---- row-split 8-wave kernel (round 3): 209 ... 256 queries at 768 < d <= 2048 -------------------------------------------------
+// ---- row-split 8-wave kernel (round 3): 209 ... 256 queries at d > 768 ------------------------------------------------------------
 // The 8-wave kernel above is LDS-bound: each wave multiplies 256 rows x 32 queries, so every A fragment feeds two MFMAs and the CU
 // reads 256 KB of LDS per K step (2048 LDS cycles against 2048 MFMA cycles).  Here the eight waves are 2 row halves x 4 query
 // quarters - a wave multiplies 128 rows x 64 queries, an A fragment feeds FOUR MFMAs - and the queries of a K step are DMA'd into
@@ -1162,10 +1162,15 @@ static int wide_waves_for(int D, int nq) {
   return (nblk == 9 || nblk == 11 || nblk == 12) ? 4 : 8;
 }
 
-// 209 ... 256 queries at 768 < d <= 2048, inner product, k <= 128: the row-split kernel (RR_WIDE_RS=0 / RR_WIDE_WAVES switch it off)
+// 209 ... 256 queries at d > 768, inner product, k <= 128: the row-split kernel (RR_WIDE_RS=0 / RR_WIDE_WAVES switch it off).
+// Measured against the kernels it replaces (scan launches, 256 queries): d = 1024 0.522-0.529 vs 0.510-0.515, 2048 0.527-0.530 vs
+// 0.512-0.521, 3072 0.521-0.524 vs 0.510-0.512, 4096 0.525-0.526 vs 0.511-0.513, 8192 0.516-0.517 vs 0.501-0.505; with 208 queries
+// or fewer the kernels that leave query quarters out win (160 queries: 0.61 against 0.52).
 bool scan_wide_rowsplit(int D, int nq, bool l2, int k) {
   static const bool on = [] { const char* e = getenv("RR_WIDE_RS"); return !(e && atoi(e) == 0) && !getenv("RR_WIDE_WAVES"); }();
-  return on && wide_pd() != 0 && !l2 && D > kMaxResidentDim && D <= 2048 && nq > 208 && k <= 128;
+  static const int max_d = [] { const char* e = getenv("RR_WIDE_RS_MAXD"); return e ? atoi(e) : kMaxDim; }();   // (tuning runs)
+  static const int min_q = [] { const char* e = getenv("RR_WIDE_RS_MINQ"); return e ? atoi(e) : 209; }();
+  return on && wide_pd() != 0 && !l2 && D > kMaxResidentDim && D <= max_d && nq >= min_q && k <= 128;
 }
 // name of the filter-launch kernel launch_scan_wide_t picks (reported by rr_flat_scan_kernel_name)
 const char* scan_wide_kernel_name(int D, int nq) {
