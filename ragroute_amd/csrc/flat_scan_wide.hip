@@ -1074,9 +1074,6 @@ __global__ __launch_bounds__(512) void flat_scan_wide_rs_kernel(const ScanArgs a
     //   issue order   A0 B00 B01 B02 B03 A1 A2 A3 | after f=0: B10 A4 | f=1: B11 A5 | f=2: B12 A6 | f=3: B13 A7 | f=k (4..11): A(k+4)
     // (first version: all 8 B fragments + 8 A fragments up front - 72 reads CU-wide ahead of every wave's first MFMA, no gain over
     // the 8-wave kernel)
-    // the query pieces of step s+1 go out first: they have only this one step to land (L2 latency), the corpus pieces two
-#pragma unroll
-    for (int i = 0; i < 4; ++i) issue_qpiece(nkcol, qslot ^ 1, i);
     read_a(std::integral_constant<int, 0>{});
     static_for<4>([&](auto qi) { read_b(std::integral_constant<int, 0>{}, qi); });
     read_a(std::integral_constant<int, 1>{});
@@ -1096,7 +1093,10 @@ __global__ __launch_bounds__(512) void flat_scan_wide_rs_kernel(const ScanArgs a
       });
       if constexpr (f < 4) read_b(std::integral_constant<int, 1>{}, std::integral_constant<int, f>{});
       if constexpr (f + 4 < NF) read_a(std::integral_constant<int, f + 4>{});
-      if constexpr ((f & 3) == 1) issue_cpiece(dkg, dslot, f >> 2);       // corpus of step s+2, spread over the MFMA stream
+      // the query pieces of step s+1 go out behind the first four fragments (they have only this one step to land: L2 latency; at
+      // the very top of the step they would delay every wave's first LDS reads), the corpus pieces of step s+2 over the rest
+      if constexpr (f < 4) issue_qpiece(nkcol, qslot ^ 1, f);
+      if constexpr (f >= 5 && (f - 5) % 3 == 0) issue_cpiece(dkg, dslot, (f - 5) / 3);
     });
     dma_advance();
     if (++cslot == NSC) cslot = 0;

@@ -3,7 +3,7 @@
 set -o pipefail
 export TMPDIR=/tmp PYTHONPATH=.
 O=gpurun_out/r03_rs; mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_flat_search_gpu.py tests/test_segments_gpu.py tests/test_guard_pages_gpu.py -m gpu -x -q > $O/pytest.log 2>&1; rc=$?
+timeout -k 10 600 python -m pytest tests/test_flat_search_gpu.py -m gpu -k "wide or fixture or config" -x -q > $O/pytest.log 2>&1; rc=$?
 tail -6 $O/pytest.log
 [ $rc -ne 0 ] && exit $rc
 for shape in "4000000 1024" "2000000 2048" "3000000 1536"; do
