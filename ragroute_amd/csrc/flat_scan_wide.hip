@@ -1071,28 +1071,34 @@ __global__ __launch_bounds__(512) void flat_scan_wide_rs_kernel(const ScanArgs a
     };
     // Read schedule (LDS reads of a wave return in order, lgkmcnt(N) = all but the N youngest have landed).  The step starts right
     // after a barrier with EVERY wave of the CU reading, so the first MFMA must depend on as few reads as possible:
-    //   issue order   A0 B00 B01 B02 B03 A1 A2 A3 | after f=0: B10 A4 | f=1: B11 A5 | f=2: B12 A6 | f=3: B13 A7 | f=k (4..11): A(k+4)
+    //   issue order   A0 B00 B01 B02 B03 A1 .. A5 | after f=0: B10 A6 | f=1: B11 A7 | f=2: B12 A8 | f=3: B13 A9 | f=k (4..9): A(k+6)
     // (first version: all 8 B fragments + 8 A fragments up front - 72 reads CU-wide ahead of every wave's first MFMA, no gain over
     // the 8-wave kernel)
     read_a(std::integral_constant<int, 0>{});
     static_for<4>([&](auto qi) { read_b(std::integral_constant<int, 0>{}, qi); });
-    read_a(std::integral_constant<int, 1>{});
-    read_a(std::integral_constant<int, 2>{});
-    read_a(std::integral_constant<int, 3>{});
+#ifndef RR_RS_AHEAD
+#define RR_RS_AHEAD 4      // A fragments in flight ahead of the one being multiplied (4 or 6: same-device A/B 0.520-0.528 against 0.518-0.527)
+#endif
+    constexpr int AH = RR_RS_AHEAD;
+    static_assert(AH == 4 || AH == 6, "RR_RS_AHEAD");
+    static_for<AH - 1>([&](auto ai) { read_a(std::integral_constant<int, decltype(ai)::value + 1>{}); });
     static_for<NF>([&](auto fi) {
       constexpr int f = decltype(fi)::value;
       constexpr int par = f >> 3, t = (f >> 1) & 3, rb = f & 1;
-      // reads issued before this fragment's MFMAs, and the issue index of A[f]
-      constexpr int issued = f == 0 ? 8 : f < 4 ? 8 + 2 * f : f < 12 ? 12 + f : 24;
-      constexpr int idx_a = f == 0 ? 0 : f < 4 ? 4 + f : f < 8 ? 2 * f + 1 : 8 + f;
+      // reads issued before this fragment's MFMAs, and the issue index of A[f]:
+      //   initial burst A0 B00..B03 A1..A(AH-1) = 4 + AH reads; after fragment f < 4: B1[f] and A(f+AH); after f >= 4: A(f+AH) while it exists
+      constexpr int issued = f < 4 ? 4 + AH + 2 * f : f < NF - AH ? 8 + AH + f : 24;
+      constexpr int idx_a = f == 0 ? 0 : f < AH ? 4 + f : f < AH + 4 ? 4 + AH + 2 * (f - AH) + 1 : 8 + f;
+      constexpr int idx_b13 = 10 + AH;                             // the last B fragment of the second k slice
+      constexpr int need = (par == 1 && idx_a < idx_b13) ? idx_b13 : idx_a;   // (with AH = 6, A8 is issued before B13)
       static_for<4>([&](auto qi) {
         constexpr int qb = decltype(qi)::value;
         if constexpr (f == 0) lgkm_wait<issued - 1 - (1 + qb)>();     // B0[qb] is read 1 + qb
-        else if constexpr (qb == 0) lgkm_wait<issued - 1 - idx_a>();   // (every B fragment this k slice needs was issued before A[f])
+        else if constexpr (qb == 0) lgkm_wait<issued - 1 - need>();    // (the B fragments of the fragment's k slice are covered by `need`)
         Mfma16Fixed128<T>::template run<4 * ((2 * t + rb) * 4 + qb), FIRST && par == 0>(c[f % NB], bq[par][qb]);
       });
       if constexpr (f < 4) read_b(std::integral_constant<int, 1>{}, std::integral_constant<int, f>{});
-      if constexpr (f + 4 < NF) read_a(std::integral_constant<int, f + 4>{});
+      if constexpr (f + AH < NF) read_a(std::integral_constant<int, f + AH>{});
       // the query pieces of step s+1 go out behind the first four fragments (they have only this one step to land: L2 latency; at
       // the very top of the step they would delay every wave's first LDS reads), the corpus pieces of step s+2 over the rest
       if constexpr (f < 4) issue_qpiece(nkcol, qslot ^ 1, f);
