@@ -64,8 +64,10 @@ int rr_rows_to_half(const float* d_x, int64_t n, int64_t d, int64_t ld_in, void*
  * (entries >= d are zero, matching the zero padding of router.py:150). */
 int rr_centroid(const void* d_xb, int dtype, int64_t n_rows, int dim, int d, float* d_out, void* stream);
 
-/* Bytes of device workspace rr_flat_search needs for this k on the current device. */
+/* Bytes of device workspace rr_flat_search (and _l2, _segments) needs for this k on the current device: for rows of any
+ * width, or — smaller for dim <= 768 — for rows of one padded width. */
 size_t rr_flat_search_workspace_bytes(int k);
+size_t rr_flat_search_workspace_bytes_for(int k, int dim);
 
 /* Exact brute-force inner-product top-k of nq queries against an HBM-resident corpus.
  * Replaces `index.search(query_embed, k)` — reference ragroute/data_source.py:158, 186, 203

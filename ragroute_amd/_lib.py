@@ -17,7 +17,7 @@ EXPORTS = ("rr_version", "rr_last_error", "rr_device_cus", "rr_padded_dim", "rr_
            "rr_flat_search_workspace_bytes", "rr_flat_search", "rr_merge_topk", "rr_router_mlp", "rr_profile_begin",
            "rr_profile_end", "rr_centroid", "rr_flat_search_l2", "rr_half_sqnorms", "rr_screen_dim", "rr_screen_build",
            "rr_flat_search_screened_workspace_bytes", "rr_flat_search_screened", "rr_router_workspace_bytes", "rr_router_mlp_ws",
-           "rr_build_flags", "rr_merge_topk_gathered", "rr_flat_scan_kernel_name", "rr_flat_search_segments")
+           "rr_build_flags", "rr_merge_topk_gathered", "rr_flat_scan_kernel_name", "rr_flat_search_segments", "rr_flat_search_workspace_bytes_for")
 
 
 class RouterWeightsStruct(ctypes.Structure):
@@ -62,6 +62,8 @@ def lib():
         L.rr_rows_to_half.argtypes = [vp, i64, i64, i64, vp, i32, i64, i32, vp]
         L.rr_flat_search_workspace_bytes.argtypes = [i32]
         L.rr_flat_search_workspace_bytes.restype = sz
+        L.rr_flat_search_workspace_bytes_for.argtypes = [i32, i32]
+        L.rr_flat_search_workspace_bytes_for.restype = sz
         L.rr_flat_search.argtypes = [vp, i32, i64, i32, vp, i32, i32, vp, vp, i64, vp, sz, vp, i64, vp]
         L.rr_merge_topk.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
         L.rr_flat_search_segments.argtypes = [vp, i32, i64, i32, ctypes.POINTER(SegmentStruct), i32, vp, i32, i32, vp, vp, vp, sz, vp, i64, vp]

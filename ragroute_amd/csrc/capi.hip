@@ -106,10 +106,11 @@ struct Workspace {
   size_t total;
 };
 
-Workspace carve(char* base, int k, int grid) {
+Workspace carve(char* base, int k, int grid, int dim) {
   using namespace rr;
   const int cap = cand_cap_for_k(k);
-  const int bpw = k <= 128 ? 8 : 4;   // candidate buffers per (workgroup, query): the row-split wide-row kernel (k <= 128) uses 8
+  // candidate buffers per (workgroup, query): 4 lane quarters; the row-split wide-row kernel (dim > 768, k <= 128) uses 8
+  const int bpw = (k <= 128 && dim > kMaxResidentDim) ? 8 : 4;
   Workspace w;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return base ? base + o : (char*)nullptr; };
@@ -180,11 +181,17 @@ int rr_centroid(const void* xb, int dtype, int64_t n_rows, int dim, int d, float
   return e == hipSuccess ? RR_OK : hip_fail(e, "rr_centroid");
 }
 
-size_t rr_flat_search_workspace_bytes(int k) {
+size_t rr_flat_search_workspace_bytes(int k) {   // any dim
   if (k < 1 || k > rr::kMaxK) return 0;
   int grid = device_cus();
   if (grid <= 0) return 0;
-  return carve(nullptr, k, grid).total;
+  return carve(nullptr, k, grid, rr::kMaxDim).total;
+}
+size_t rr_flat_search_workspace_bytes_for(int k, int dim) {
+  if (k < 1 || k > rr::kMaxK || rr::scan_padded_dim(dim) != dim) return 0;
+  int grid = device_cus();
+  if (grid <= 0) return 0;
+  return carve(nullptr, k, grid, dim).total;
 }
 
 // segs != nullptr: segmented search — xb is ONE matrix of n_rows rows holding several sources (segs->row_begin / row_limit),
@@ -204,8 +211,8 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
   if (!xq || !D || !I || !ws || (!xb && n_rows > 0)) return fail(RR_ERR_INVALID, "rr_flat_search: null pointer%s");
   const int grid = device_cus();
   if (grid <= 0) return fail(RR_ERR_HIP, "rr_flat_search: no HIP device%s");
-  Workspace w = carve((char*)ws, k, grid);
-  if (ws_bytes < w.total) return fail(RR_ERR_WORKSPACE, "rr_flat_search: workspace smaller than rr_flat_search_workspace_bytes(k)%s");
+  Workspace w = carve((char*)ws, k, grid, dtype == kDtypeI8 ? kMaxResidentDim : dim);
+  if (ws_bytes < w.total) return fail(RR_ERR_WORKSPACE, "rr_flat_search: workspace smaller than rr_flat_search_workspace_bytes_for(k, dim)%s");
 
   read_schedule_env();
   const int cap = cand_cap_for_k(k);
@@ -383,7 +390,7 @@ static ScreenWs carve_screen(char* base, int list_len, int nq, int dim8, int gri
   w.qinfo = (float*)take((size_t)nq * 2 * sizeof(float));
   w.PL = (float*)take((size_t)nq * list_len * sizeof(float));
   w.IL = (int64_t*)take((size_t)nq * list_len * sizeof(int64_t));
-  w.inner_bytes = carve(nullptr, list_len, grid).total;
+  w.inner_bytes = carve(nullptr, list_len, grid, rr::kMaxResidentDim).total;
   w.inner = take(w.inner_bytes);
   w.total = off;
   return w;

@@ -194,7 +194,7 @@ class FlatIndex:
     def _workspace(self, k):
         ws = self._ws.get(k)
         if ws is None:
-            nbytes = lib().rr_flat_search_workspace_bytes(k)
+            nbytes = lib().rr_flat_search_workspace_bytes_for(k, self.dim)
             if nbytes == 0:
                 raise ValueError(f"k must be in [1, {_lib.RR_MAX_K}], got {k}")
             self._ws = {k: torch.empty(nbytes, dtype=torch.uint8, device=self.device)}

@@ -230,3 +230,13 @@ def test_torch_ops_reach_the_segmented_search_and_the_in_place_merge(gpu):
     from oracle import oracle as O
     Dw, Iw = O.merge_topk(np.concatenate([Dr, Dr], 1), np.concatenate([Ir, Ir], 1), 10, True)
     assert np.array_equal(I2.cpu().numpy(), Iw) and np.array_equal(D2.cpu().numpy(), Dw)
+
+
+def test_workspace_size_by_width(gpu):
+    """Rows up to 768 wide need 4 candidate buffers per workgroup and query, wider rows 8 (the row-split kernel, k <= 128):
+    rr_flat_search_workspace_bytes_for sizes for one width, rr_flat_search_workspace_bytes for any."""
+    from ragroute_amd import _lib
+    L = _lib.lib()
+    a, b, c = L.rr_flat_search_workspace_bytes_for(32, 768), L.rr_flat_search_workspace_bytes_for(32, 1024), L.rr_flat_search_workspace_bytes(32)
+    assert 0 < a < b == c
+    assert L.rr_flat_search_workspace_bytes_for(32, 1000) == 0 and L.rr_flat_search_workspace_bytes_for(300, 1024) == L.rr_flat_search_workspace_bytes_for(300, 768)
