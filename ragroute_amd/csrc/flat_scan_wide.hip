@@ -1,6 +1,12 @@
-// K1 for wide rows: flat_scan_wide_kernel (d > 1536, and more than 128 queries or the L2 metric at 768 < d <= 1536).
+// K1 for wide rows (d > 1536, and more than 128 queries or the L2 metric at 768 < d <= 1536).
 // Replaces the arithmetic inside `index.search(query_embed, k)` (reference ragroute/data_source.py:158,186,203) for
 // FeB4RAG's 1024- and 4096-wide encoders (config.py:45-57, 92-96).  Split from flat_scan.hip (the query-resident kernels).
+// Kernels in this file (launch_scan_wide_t picks one):
+//   flat_scan_wide_rs_kernel  209 ... 256 queries, inner product, k <= 128 (round 3): 8 waves = 2 row halves x 4 query quarters, the
+//                             query columns of a K step DMA'd into LDS once per CU
+//   flat_scan_wide8_kernel    d <= 2048, up to 208 queries (and the L2 metric): 8 waves, queries streamed into registers
+//   flat_scan_wide_pd_kernel  d > 2048 up to 208 queries, 9 / 11 / 12 query blocks at d <= 2048, every dense (sample) launch: 4 waves
+//   flat_scan_wide_kernel     round 1's form (RR_WIDE_PD=0, A/B runs)
 #include "flat_scan_common.h"
 
 namespace rr {
