@@ -15,6 +15,12 @@ candidates] -> cross-shard merge (K4).  One process per GPU.
                    N-shard federation, printed beside it.
   --scaling strong SURVEY.md §8e (the >= 6x target): the federation is fixed at --total-shards (8) x 10M rows; rank r
                    holds shards r, r+N, ...; `value` = `federation_queries_per_sec` = 256*K/t.
+  --workload feb4rag|medrag   BASELINE configs 4 / 3 at the federations' REAL shapes (13 BEIR corpora 768 / 1024 / 4096 wide, k = 10;
+                   MedRAG's 4 corpora, k = 32; synthetic embeddings, tools/workloads.py) placed on the N GPUs by
+                   ragroute_amd/placement.py: balanced row slices, the pieces of one encoder on a rank searched in one pass.
+                   Fixed federation = strong scaling; `value` = queries/sec against the whole federation.
+Every N > 1 line carries `per_rank_scan_ms` / `per_rank_local_ms` (each rank's scan-launch time and its whole local work per step,
+one small all_gather after the timed region): a slow rank is visible.
 Every line also carries `exchange_ms` / `merge_ms` (HIP events around the all_gather and the merge, mean per step on rank 0)
 and `rccl_ranks` (dist.get_world_size() after init_process_group; 1 without a process group).
 
@@ -46,11 +52,14 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--workload", default="headline", choices=["headline", "feb4rag", "medrag"],
+                    help="headline: equal synthetic 10M x 768 shards (BASELINE metric); feb4rag / medrag: the federation at its real shapes, sliced over the GPUs")
+    ap.add_argument("--placement", default="sliced", choices=["sliced", "whole"], help="--workload feb4rag|medrag: balanced row slices, or source s -> GPU s mod G")
     ap.add_argument("--total-shards", type=int, default=8, help="--scaling strong: shards of the fixed federation")
     ap.add_argument("--rows", type=int, default=10_000_000, help="corpus rows per shard")
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--k", type=int, default=32)
+    ap.add_argument("--k", type=int, default=None, help="default: 32 (headline), the dataset's K (config.py:97-101) for --workload")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustained-seconds", type=float, default=2.0,
@@ -140,40 +149,75 @@ def main():
     from ragroute_amd.pipeline import RetrievalPipeline
     from ragroute_amd.router import CorpusRoutingNN, FoldedRouter
 
-    d, B, k, n = args.dim, args.batch, args.k, args.rows
-    tdt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
-    strong = args.scaling == "strong"
-    C = args.total_shards if strong else world                     # sources of the federation = router outputs
-    my_shards = list(range(rank, C, world)) if strong else [rank]  # shard s -> GPU s mod G
-    slots = -(-C // world)
-    shards = []
-    for sid in my_shards:
-        idx = FlatIndex(d, metric="ip", dtype=args.dtype, device=dev)
-        idx.adopt(make_shard(torch, n, d, idx.dim, tdt, 1234 + sid, dev))
-        shards.append(idx)
-
-    g = torch.Generator(device=dev)
-    g.manual_seed(4321)  # same queries on every rank
-    xq = torch.randn((B, d), generator=g, device=dev)
-    xq /= xq.norm(dim=1, keepdim=True)
-
-    # router: CorpusRoutingNN over the C sources, default init seed 0, centroid = mean of each shard's first 100k rows,
-    # identity scaler; folded into the fused kernel's weights
-    cen_mine = torch.zeros((slots, d), dtype=torch.float32, device=dev)
-    for j, idx in enumerate(shards):
-        cen_mine[j] = idx.xb[: min(n, 100_000), :d].float().mean(0)
-    if world > 1:
-        on_dev = backend == "nccl"
-        cens = torch.empty(world * slots * d, dtype=torch.float32, device=dev if on_dev else "cpu")
-        dist.all_gather_into_tensor(cens, cen_mine.view(-1) if on_dev else cen_mine.cpu().view(-1))
-        cens = cens.view(world, slots, d).cpu().numpy()
+    fed_mode = args.workload != "headline"
+    B = args.batch
+    if fed_mode:
+        # BASELINE configs 3 / 4 at the federation's real shapes, placed on the `world` GPUs by the planner
+        from ragroute_amd import config as RC
+        from ragroute_amd import placement as PL
+        from tools import workloads as W
+        k = args.k if args.k is not None else RC.K[args.workload]
+        fed = PL.federation(args.workload)
+        plan = PL.plan(fed, world) if args.placement == "sliced" else PL.whole_source_plan(fed, world)
+        pipe = RetrievalPipeline.from_placement(plan, rank, fill_half=W.fill_half, device=dev)
+        cen = W.local_centroids(args.workload, fed, pipe, dev)
+        if world > 1:
+            if backend == "nccl":
+                dist.all_reduce(cen)
+            else:
+                c = cen.cpu()
+                dist.all_reduce(c)
+                cen = c.to(dev)
+        pipe.router = W.router_for(args.workload, fed, cen.cpu().numpy(), dev)
+        emb = W.query_embeddings(fed, B, dev)
+        xq, xq_router = W.queries_by_source(fed, emb), W.pack_router_input(args.workload, fed, emb, dev)
+        my_slices = [sl for u in plan.ranks[rank] for sl in u.slices]
+        n_units = max(1, len(pipe.units))
+        # SURVEY §8(d) per unit: rows x padded width x 2 + the unit's query block and result
+        alg_bytes = sum(sl.n_rows * plan.sources[sl.sid].row_bytes for sl in my_slices) + \
+            sum(B * u[1].dim * 2 + B * k * 12 for u in pipe.units)
+        flops = sum(2.0 * B * sl.n_rows * plan.sources[sl.sid].row_bytes / 2 for sl in my_slices)
+        first_dim = pipe.units[0][1].dim if pipe.units else 0
+        strong, C = True, len(fed)
     else:
-        cens = cen_mine[None].cpu().numpy()
-    cen_all = np.stack([cens[s % world, s // world] for s in range(C)]) if strong else np.stack([cens[r, 0] for r in range(world)])
-    net = CorpusRoutingNN(2 * d + C, seed=0)
-    router = FoldedRouter.fold(net.state_dict(), cen_all, list(range(C)), C, d, [0] * C, 0.5, device=dev)
-    xq_router = xq[:, None, :].contiguous()
-    pipe = RetrievalPipeline(shards, my_shards, router=router, slots=slots)
+        d, k, n = args.dim, args.k if args.k is not None else 32, args.rows
+        tdt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+        strong = args.scaling == "strong"
+        C = args.total_shards if strong else world                     # sources of the federation = router outputs
+        my_shards = list(range(rank, C, world)) if strong else [rank]  # shard s -> GPU s mod G
+        slots = -(-C // world)
+        shards = []
+        for sid in my_shards:
+            idx = FlatIndex(d, metric="ip", dtype=args.dtype, device=dev)
+            idx.adopt(make_shard(torch, n, d, idx.dim, tdt, 1234 + sid, dev))
+            shards.append(idx)
+
+        g = torch.Generator(device=dev)
+        g.manual_seed(4321)  # same queries on every rank
+        xq = torch.randn((B, d), generator=g, device=dev)
+        xq /= xq.norm(dim=1, keepdim=True)
+
+        # router: CorpusRoutingNN over the C sources, default init seed 0, centroid = mean of each shard's first 100k rows,
+        # identity scaler; folded into the fused kernel's weights
+        cen_mine = torch.zeros((slots, d), dtype=torch.float32, device=dev)
+        for j, idx in enumerate(shards):
+            cen_mine[j] = idx.xb[: min(n, 100_000), :d].float().mean(0)
+        if world > 1:
+            on_dev = backend == "nccl"
+            cens = torch.empty(world * slots * d, dtype=torch.float32, device=dev if on_dev else "cpu")
+            dist.all_gather_into_tensor(cens, cen_mine.view(-1) if on_dev else cen_mine.cpu().view(-1))
+            cens = cens.view(world, slots, d).cpu().numpy()
+        else:
+            cens = cen_mine[None].cpu().numpy()
+        cen_all = np.stack([cens[s % world, s // world] for s in range(C)]) if strong else np.stack([cens[r, 0] for r in range(world)])
+        net = CorpusRoutingNN(2 * d + C, seed=0)
+        router = FoldedRouter.fold(net.state_dict(), cen_all, list(range(C)), C, d, [0] * C, 0.5, device=dev)
+        xq_router = xq[:, None, :].contiguous()
+        pipe = RetrievalPipeline(shards, my_shards, router=router, slots=slots)
+        n_units = len(shards)
+        alg_bytes = len(shards) * (n * d * 2 + B * d * 2 + B * k * 12)  # SURVEY §8(d), per step on this rank
+        flops = 2.0 * B * n * d * len(shards)
+        first_dim = shards[0].dim
 
     def step():  # K3 router -> K0 convert -> K1/K2 scan+top-k (route mask folded in) -> all_gather (N>1) -> K4 merge
         return pipe.search(xq, k, xq_models=xq_router)
@@ -191,7 +235,7 @@ def main():
         fence()
         # scan launches per shard and step: bootstrap + up to 8 chunks (capi.hip chunk_schedule), per 256-query block;
         # rr_profile_end FAILS if a launch went unrecorded, so the roofline cannot be overstated by a short buffer
-        check(lib().rr_profile_begin(n_steps * 10 * len(shards) * (-(-B // 256)) + 16), "rr_profile_begin")
+        check(lib().rr_profile_begin(n_steps * 12 * n_units * (-(-B // 256)) + 16), "rr_profile_begin")
         t0 = time.perf_counter()
         for i in range(n_steps):
             if with_events:
@@ -218,53 +262,83 @@ def main():
     for _ in range(min(10, max(3, args.steps))):
         step()
     exchange_ms, merge_ms = pipe.stage_ms()
+    local_ms = pipe.local_ms()
     pipe.time_stages(False)
     fence()
+    # every rank's scan-launch time per step (timed region) and whole local work per step (the extra steps): a slow rank shows
+    mine = torch.tensor([scan_ms / args.steps, local_ms, alg_bytes / 1e9], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    if world > 1:
+        per_rank = torch.empty(world * 3, dtype=torch.float64, device=mine.device)
+        dist.all_gather_into_tensor(per_rank, mine)
+        per_rank = per_rank.view(world, 3).cpu().tolist()
+    else:
+        per_rank = [mine.cpu().tolist()]
     rccl_ranks = dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1
 
     sustained = None
     if args.sustained_seconds > 0:
         est = elapsed / args.steps
-        n_sus = max(500, int(args.sustained_seconds / est) + 1)
+        n_sus = max(100 if fed_mode else 500, int(args.sustained_seconds / est) + 1)
         s_elapsed, s_scan_ms, s_launch, _ = timed(n_sus, False)
         sustained = (n_sus, s_elapsed, s_scan_ms, s_launch)
 
     if rank == 0:
         K = args.steps
-        S = len(shards)
         units = B if strong else world * B                 # queries per step the whole job answers (weak: query x shard)
-        alg_bytes = S * (n * d * 2 + B * d * 2 + B * k * 12)  # SURVEY §8(d), per step on this rank
-        flops = 2.0 * B * n * d * S
         launches_per_step = n_launch / K
         achieved = alg_bytes * K / (scan_ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not fed_mode:
             tj = json.load(open(tpath))
             if (tj.get("rows") == n and tj.get("dim") == d and tj.get("batch") == B and tj.get("dtype", "fp16") == args.dtype
                     and tj.get("k", 32) == k and tj.get("lib_version", lib().rr_version()) == lib().rr_version()):
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_source = "profiles/traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured in this run)"
-        shape = f"{n} x {d} {args.dtype} rows per shard"
-        layout = (f"{C} shards fixed, {S} per GPU (strong scaling)" if strong else "one shard per GPU (weak scaling)")
+        if fed_mode:
+            total_rows = sum(s_.rows for s_ in fed)
+            total_gb = sum(s_.rows * s_.row_bytes for s_ in fed) / 1e9
+            config = {"workload": f"{args.workload}: {C} sources at their real row counts and encoder widths ({total_rows} rows, {total_gb:.1f} GB fp16), "
+                                  f"{'balanced row slices (placement.plan)' if args.placement == 'sliced' else 'source s -> GPU s mod G'} over {world} GPU(s), "
+                                  f"query batch {B}, k={k}, router MLP + per-unit exact top-k + ONE all_gather + merge",
+                      "dataset": args.workload, "placement": args.placement, "rows_total": total_rows, "corpus_GB": round(total_gb, 2), "batch": B, "k": k,
+                      "sources": C, "units_per_rank": [len(u) for u in plan.ranks], "exchange_slots": pipe.slots,
+                      "predicted_ms_per_rank": [round(t, 3) for t in plan.predicted_ms],
+                      "parallelism": f"{C} sources in {sum(len(u.slices) for us in plan.ranks for u in us)} row slices over {world} gpu(s)",
+                      "unit_definition": "queries per second against the whole fixed federation (= federation_queries_per_sec)",
+                      "timing": "ms_per_step = wall clock of the K steps between fences / K; median/p10/p90 = one HIP-event pair per step"}
+        else:
+            S = len(shards)
+            shape = f"{n} x {d} {args.dtype} rows per shard"
+            layout = (f"{C} shards fixed, {S} per GPU (strong scaling)" if strong else "one shard per GPU (weak scaling)")
+            config = {"workload": f"{shape}, {layout}, query batch {B}, k={k}, exact inner-product top-k + router MLP over "
+                                  f"{C} source(s) + cross-shard merge",
+                      "rows_per_shard": n, "dim": d, "batch": B, "k": k, "shards_total": C, "shards_per_gpu": S,
+                      "parallelism": f"shard-per-gpu x{world}" if not strong else f"{C} shards over {world} gpu(s)",
+                      "unit_definition": ("queries per second against the whole fixed federation (= federation_queries_per_sec)" if strong else
+                                          f"(query x {n}-row shard) PAIRS searched per second, whole job = N x federation_queries_per_sec "
+                                          "(N=1: queries/sec on one shard, the BASELINE configuration); federation_queries_per_sec = "
+                                          "queries answered per second against all N shards"),
+                      "timing": "ms_per_step = wall clock of the K steps between fences / K; median/p10/p90 = one HIP-event pair per step"}
+        scans = [r[0] for r in per_rank]
+        locals_ = [r[1] for r in per_rank]
         res = {
             "metric": METRIC, "value": round(units * K / elapsed, 1), "unit": "queries/sec", "n_gpus": world, "steps": K,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if fed_mode else args.scaling,
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "median_ms": round(percentile(per_step, 0.5), 4), "p10_ms": round(percentile(per_step, 0.1), 4),
             "p90_ms": round(percentile(per_step, 0.9), 4),
             "federation_queries_per_sec": round(B * K / elapsed, 1), "exchange_ms": round(exchange_ms, 4), "merge_ms": round(merge_ms, 4),
+            "per_rank_scan_ms": {"min": round(min(scans), 4), "max": round(max(scans), 4), "mean": round(sum(scans) / len(scans), 4),
+                                 "ranks": [round(v, 4) for v in scans]},
+            "per_rank_local_ms": {"min": round(min(locals_), 4), "max": round(max(locals_), 4), "mean": round(sum(locals_) / len(locals_), 4),
+                                  "max_over_mean": round(max(locals_) / (sum(locals_) / len(locals_)), 4), "ranks": [round(v, 4) for v in locals_],
+                                  "what": "router + query conversion + every local scan, HIP events up to the exchange, mean of the steps after the timed region"},
+            "per_rank_corpus_GB": [round(r[2], 3) for r in per_rank],
             "rccl_ranks": rccl_ranks, "exchange_backend": (backend if world > 1 else "none (one rank: the merge reads the local buffer)"),
-            "config": {"workload": f"{shape}, {layout}, query batch {B}, k={k}, exact inner-product top-k + router MLP over "
-                                   f"{C} source(s) + cross-shard merge",
-                       "rows_per_shard": n, "dim": d, "batch": B, "k": k, "shards_total": C, "shards_per_gpu": S,
-                       "parallelism": f"shard-per-gpu x{world}" if not strong else f"{C} shards over {world} gpu(s)",
-                       "unit_definition": ("queries per second against the whole fixed federation (= federation_queries_per_sec)" if strong else
-                                           f"(query x {n}-row shard) PAIRS searched per second, whole job = N x federation_queries_per_sec "
-                                           "(N=1: queries/sec on one shard, the BASELINE configuration); federation_queries_per_sec = "
-                                           "queries answered per second against all N shards"),
-                       "timing": "ms_per_step = wall clock of the K steps between fences / K; median/p10/p90 = one HIP-event pair per step"},
-            "roofline": {"bound": "hbm", "kernel": lib().rr_flat_scan_kernel_name(shards[0].dim, B).decode(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "config": config,
+            "roofline": {"bound": "hbm", "kernel": lib().rr_flat_scan_kernel_name(first_dim, B).decode() if first_dim else None, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": round(alg_bytes / launches_per_step),
                          "avg_launch_ms": round(scan_ms / max(1, n_launch), 4), "launches_per_step": round(launches_per_step, 2),
@@ -280,7 +354,7 @@ def main():
                 "value": round(units * n_sus / s_elapsed, 1), "avg_launch_ms": round(s_scan_ms / max(1, s_launch), 4),
                 "achieved": round(alg_bytes * n_sus / (s_scan_ms * 1e-3) / 1e9, 1),
                 "frac": round(alg_bytes * n_sus / (s_scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not fed_mode:
             res["cpu_baseline"] = cpu_baseline(shards[0], xq, n, d, k)
         print(json.dumps(res), flush=True)
     if world > 1:

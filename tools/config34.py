@@ -1,6 +1,12 @@
 """BASELINE configs 3 and 4 at their real corpus SHAPES on one MI355X (synthetic embeddings, resident in HBM).
 
     python tools/config34.py medrag|feb4rag [batches] [per-source|segments]
+    python tools/config34.py medrag|feb4rag [batches] --plan G [--whole] [--with-one]
+
+  --plan G: the G-GPU layout of ragroute_amd/placement.py (balanced row slices; --whole: source s -> GPU s mod G) rehearsed on ONE
+  GPU: each rank's units are built, timed (router + local scans + merge over G x slots x k candidates) and freed in turn; prints
+  every rank's unit list, predicted and measured ms, max / mean, and with --with-one the one-GPU step of the same federation
+  (= the strong-scaling ratio the layout can reach: the exchange of G x slots x B x k x 12 bytes is not in it).
 
   segments (default): sources that share an encoder (config.py:37-71) live in one SegmentedIndex and are searched in ONE pass
   (rr_flat_search_segments); per-source: one search per source, as in round 2.
@@ -48,10 +54,76 @@ def make(n, d, dim, seed, dev, out=None):
     return xb
 
 
+def timed_events(fn, n):
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return sorted(a.elapsed_time(b) for a, b in evs)
+
+
+def plan_mode(dataset, batches, G, whole, with_one):
+    from ragroute_amd import placement as P
+    from ragroute_amd.sharded import alloc_packed, merge_gathered
+    from tools import workloads as W
+    dev = torch.device("cuda:0")
+    fed = P.federation(dataset)
+    k, B = C.K[dataset], 256
+    cen = torch.zeros((len(fed), C.EMBEDDING_MAX_LENGTH[dataset]), device=dev)
+    for i, src in enumerate(fed):        # centroid = mean of the source's first 100k rows, straight from the generator
+        n = min(src.rows, 100_000)
+        tmp = torch.zeros((n, src.dim), dtype=torch.float16, device=dev)
+        W.fill_half(src, P.RowSlice(src.sid, 0, n), tmp)
+        cen[i, : src.dim] = tmp.float().mean(0)
+        del tmp
+    router = W.router_for(dataset, fed, cen.cpu().numpy(), dev)
+    emb = W.query_embeddings(fed, B, dev)
+    xq, xq_models = W.queries_by_source(fed, emb), W.pack_router_input(dataset, fed, emb, dev)
+
+    def run(plan):
+        out = []
+        for r in range(len(plan.ranks)):
+            pipe = RetrievalPipeline.from_placement(plan, r, fill_half=W.fill_half, router=router, device=dev)
+            step = lambda: pipe.search(xq, k, xq_models=xq_models)   # noqa: E731
+            for _ in range(3):
+                step()
+            ms = timed_events(step, batches)
+            out.append({"rank": r, "measured_ms": round(ms[len(ms) // 2], 4), "p90_ms": round(ms[(len(ms) * 9) // 10], 4),
+                        "predicted_ms": round(plan.predicted_ms[r], 4),
+                        "corpus_GB": round(sum(sl.n_rows * plan.sources[sl.sid].row_bytes for u in plan.ranks[r] for sl in u.slices) / 1e9, 3),
+                        "units": plan.describe()[r]["units"]})
+            del pipe, step
+            torch.cuda.empty_cache()
+        return out
+
+    plan = P.whole_source_plan(fed, G) if whole else P.plan(fed, G)
+    ranks = run(plan)
+    meas = [r["measured_ms"] for r in ranks]
+    # the G-rank merge (every rank runs it after the exchange): G x slots x k candidates per query, read in place
+    buf, _, _ = alloc_packed(B, k, dev, plan.slots)
+    gathered = buf[None].expand(G, -1).contiguous()
+    mm = timed_events(lambda: merge_gathered(gathered, B, k, plan.slots, k, True), 20)
+    res = {"config": f"{dataset}: {len(fed)} sources at their real shapes, {'source s -> GPU s mod G' if whole else 'balanced row slices (placement.plan)'} "
+                     f"for G={G}, every rank's step (router + local scans + 1-rank merge) timed in turn on ONE MI355X, B={B}, k={k}",
+           "G": G, "exchange_slots": plan.slots, "max_ms": max(meas), "mean_ms": round(sum(meas) / G, 4), "max_over_mean": round(max(meas) / (sum(meas) / G), 4),
+           "predicted_max_ms": round(max(plan.predicted_ms), 4), "merge_of_G_ranks_ms": round(mm[len(mm) // 2], 4),
+           "exchange_bytes_per_rank": plan.slots * B * k * 12, "ranks": ranks}
+    if with_one:
+        one = run(P.plan(fed, 1))[0]
+        res["one_gpu_ms"] = one["measured_ms"]
+        res["one_gpu_units"] = len(one["units"])
+        res["predicted_speedup_at_G"] = round(one["measured_ms"] / (max(meas) + res["merge_of_G_ranks_ms"]), 3)
+    print(json.dumps(res))
+
+
 def main():
     dataset = sys.argv[1] if len(sys.argv) > 1 else "medrag"
     batches = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     mode = sys.argv[3] if len(sys.argv) > 3 else "segments"
+    if "--plan" in sys.argv:
+        return plan_mode(dataset, batches, int(sys.argv[sys.argv.index("--plan") + 1]), "--whole" in sys.argv, "--with-one" in sys.argv)
     dev = torch.device("cuda:0")
     sources = C.DATA_SOURCES[dataset]
     model_of = {s: C.EMBEDDING_MODELS_PER_DATA_SOURCE[dataset][s][0] for s in sources}
