@@ -260,7 +260,14 @@ def main():
     # exchange / merge time per step: a few extra steps AFTER the timed region (the three event records per step stay out of `value`)
     pipe.time_stages(True)
     for _ in range(min(10, max(3, args.steps))):
-        step()
+        D_chk, I_chk = step()
+    # checksums of the answer (the same on every rank), taken AFTER the timed region (their host reads idle the GPU for a moment,
+    # and the steps right after such a pause run slower): for --workload the corpus is a pure function of (source, row), so the
+    # line of ANY placement / GPU count must carry the same three numbers
+    wts = 1 + torch.arange(I_chk.shape[1], device=dev, dtype=torch.int64)
+    checksum = {"ids_sum": int(I_chk.sum()), "ids_rank_weighted": int((I_chk % 1000003 * wts).sum()),
+                "score_sum": round(float(D_chk.double().masked_fill(~torch.isfinite(D_chk), 0.0).sum()), 6)}   # (padding scores are -inf)
+    del D_chk, I_chk
     exchange_ms, merge_ms = pipe.stage_ms()
     local_ms = pipe.local_ms()
     pipe.time_stages(False)
@@ -335,7 +342,7 @@ def main():
             "per_rank_local_ms": {"min": round(min(locals_), 4), "max": round(max(locals_), 4), "mean": round(sum(locals_) / len(locals_), 4),
                                   "max_over_mean": round(max(locals_) / (sum(locals_) / len(locals_)), 4), "ranks": [round(v, 4) for v in locals_],
                                   "what": "router + query conversion + every local scan, HIP events up to the exchange, mean of the steps after the timed region"},
-            "per_rank_corpus_GB": [round(r[2], 3) for r in per_rank],
+            "per_rank_corpus_GB": [round(r[2], 3) for r in per_rank], "result_checksum": checksum,
             "rccl_ranks": rccl_ranks, "exchange_backend": (backend if world > 1 else "none (one rank: the merge reads the local buffer)"),
             "config": config,
             "roofline": {"bound": "hbm", "kernel": lib().rr_flat_scan_kernel_name(first_dim, B).decode() if first_dim else None, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

@@ -58,11 +58,11 @@ hipError_t profiled_scan(const rr::ScanArgs& a, int dtype, int D, bool dense, in
 int g_sample_rows = rr::kSampleRows, g_chunk_growth = 0;  // 0 = size-aware schedule
 void read_schedule_env() {
   static const bool once = [] {
-    if (const char* v = getenv("RR_SAMPLE_ROWS")) {
+    if (const char* v = rr::tuning_env("RR_SAMPLE_ROWS")) {
       int r = atoi(v) / rr::kTileRows * rr::kTileRows;
       if (r >= 1024 && r <= rr::kSampleRows) g_sample_rows = r;
     }
-    if (const char* v = getenv("RR_CHUNK_GROWTH")) {
+    if (const char* v = rr::tuning_env("RR_CHUNK_GROWTH")) {
       int g = atoi(v);
       if (g >= 2 && g <= 1024) g_chunk_growth = g;
     }
@@ -306,7 +306,7 @@ static int flat_search_impl(const void* xb, int dtype, int64_t n_rows, int dim, 
         if (end <= begin) end = begin + 8;
         if (end > total_tiles) end = total_tiles;
         a.tile_first = (uint32_t)begin; a.tile_stride = 1; a.n_tiles = (uint32_t)(end - begin);
-        a.timeline = getenv("RR_SCAN_TIMELINE") ? (uint64_t*)w.dense : nullptr;  // the dense buffer is idle during chunk scans
+        a.timeline = rr::tuning_env("RR_SCAN_TIMELINE") ? (uint64_t*)w.dense : nullptr;  // the dense buffer is idle during chunk scans
         RR_CHECK(profiled_scan(a, dtype, dim, false, grid, st), "rr_flat_search/scan");
         const bool last = end == total_tiles;
         RR_CHECK(launch_compact(s, (last && !half_sqnorm) ? &fin : nullptr, st), "rr_flat_search/compact");
@@ -355,7 +355,9 @@ int rr_flat_search_segments(const void* xb, int dtype, int64_t n_rows_total, int
   int max_col = -1;
   for (int s = 0; s < n_segs; ++s) {
     const rr_segment& g = segs[s];
-    if (g.n_rows < 0 || g.row_begin < prev_end || g.row_begin % RR_SEGMENT_ALIGN != 0 || g.row_begin + g.n_rows > n_rows_total)
+    // (row_begin <= n_rows_total is checked first, so the subtraction cannot overflow whatever n_rows is)
+    if (g.n_rows < 0 || g.row_begin < prev_end || g.row_begin % RR_SEGMENT_ALIGN != 0 || g.row_begin > n_rows_total ||
+        g.n_rows > n_rows_total - g.row_begin)
       return fail(RR_ERR_INVALID, "rr_flat_search_segments: segments must be ascending, non-overlapping, inside the matrix, and begin at "
                                   "multiples of 256 rows%s");
     if (g.mask_col < -1) return fail(RR_ERR_INVALID, "rr_flat_search_segments: mask_col must be >= -1%s");

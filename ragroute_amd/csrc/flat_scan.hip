@@ -37,7 +37,10 @@ namespace rr {
 #ifndef RR_SCAN_STAGGER
 #define RR_SCAN_STAGGER 0
 #endif
-template <typename T, int D, bool DENSE, bool NT = false, bool L2 = false>
+// SEG = true: the launch is a chunk of a segmented search (a.ranges: one run of tiles per segment, a TileCursor per stream).  Plain
+// searches run the SEG = false instantiation, whose tile arithmetic and epilogue carry nothing of that (round 4: the same-device
+// A/B against round 2's kernel priced the run-time form at 0.5 - 0.8 % of the headline's scan launch, profiles/r04/headline_ab.json).
+template <typename T, int D, bool DENSE, bool NT = false, bool L2 = false, bool SEG = false>
 __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   typedef typename Mfma<T>::frag frag;
   constexpr int KS2 = D / 32;        // 32-wide k slices
@@ -72,10 +75,10 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
   const int f_w = ((rho_w >> 1) & 3) | ((wave & 1) << 2);
   const int c_w = sig ^ f_w;
   TileCursor dcur;   // the DMA stream's position in the launch's tile runs (segmented search; plain: tile_first + j * tile_stride)
-  cursor_init(a, dcur);
+  if (SEG) cursor_init(a, dcur);
   auto tile_src = [&](uint32_t j) -> const char* {
     if (j >= a.n_tiles) j = a.n_tiles - 1;
-    const uint32_t tile = cursor_tile(a, dcur, j);
+    const uint32_t tile = SEG ? cursor_tile(a, dcur, j) : a.tile_first + j * a.tile_stride;
     uint32_t row = tile * kTileRows + wave * 8 + rho_w;
     row = row < a.n_rows ? row : a.n_rows - 1;
     return (const char*)a.xb + (size_t)row * (D * 2) + c_w * 16;
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256, 1) void flat_scan16_kernel(const ScanArgs a) {
           acc[1][qb] -= h1;
         }
       }
-      tile_epilogue16<DENSE, NQB, 64, false, 4, true>(a, st, acc, j, lane, wave);
+      tile_epilogue16<DENSE, NQB, 64, false, 4, true, SEG>(a, st, acc, j, lane, wave);
     };
     if (nb >= 4) {
       compute(std::integral_constant<int, 4>{});
@@ -508,9 +511,9 @@ int g_generic_tall = 16;       // 16 = flat_scan_wide_kernel; 8 / 4 / 0: compile
 
 static void read_variant_env() {
   static const bool env_read = [] {
-    if (const char* v = getenv("RR_SCAN_VARIANT")) g_scan_variant = atoi(v);
-    if (const char* v = getenv("RR_GENERIC_TALL")) g_generic_tall = atoi(v);
-    if (const char* v = getenv("RR_WIDE_MIN_QUERIES")) g_wide_min_queries = atoi(v);
+    if (const char* v = tuning_env("RR_SCAN_VARIANT")) g_scan_variant = atoi(v);
+    if (const char* v = tuning_env("RR_GENERIC_TALL")) g_generic_tall = atoi(v);
+    if (const char* v = tuning_env("RR_WIDE_MIN_QUERIES")) g_wide_min_queries = atoi(v);
 #ifndef RR_DEV_VARIANTS
     if (g_scan_variant != 15) g_scan_variant = 16;  // the development kernels are not in this build
     g_generic_tall = 16;
@@ -549,18 +552,22 @@ int scan_bufs_per_wg(int D, int nq, bool l2, int k) {
   return scan_wide_rowsplit(D, nq, l2, k) ? 8 : 4;
 }
 
-template <typename T, int D, bool DENSE, bool NT = false, bool L2 = false>
+template <typename T, int D, bool DENSE, bool NT = false, bool L2 = false, bool SEG = false>
 static hipError_t launch_scan16(const ScanArgs& a, int grid, hipStream_t st) {
   const size_t lds = scan16_slots(D) * ((size_t)kTileRows * D * 2 + 256);  // ring + L2 norm slots
-  hipError_t e = hipFuncSetAttribute((const void*)flat_scan16_kernel<T, D, DENSE, NT, L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute((const void*)flat_scan16_kernel<T, D, DENSE, NT, L2, SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((flat_scan16_kernel<T, D, DENSE, NT, L2>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((flat_scan16_kernel<T, D, DENSE, NT, L2, SEG>), dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
 template <typename T, int D>
 static hipError_t launch_scan_t(const ScanArgs& a, bool dense, int grid, hipStream_t st) {
   const bool nt = (size_t)a.n_rows * D * 2 > kNtThresholdBytes && g_scan_variant != 15;
+  if (a.ranges) {       // chunk launch of a segmented search (inner product, filter launches only)
+    if (a.half_sqnorm || dense) return hipErrorNotSupported;
+    return nt ? launch_scan16<T, D, false, true, false, true>(a, grid, st) : launch_scan16<T, D, false, false, false, true>(a, grid, st);
+  }
   if (a.half_sqnorm) {  // L2 metric
     if (dense) return launch_scan16<T, D, true, false, true>(a, grid, st);
     return nt ? launch_scan16<T, D, false, true, true>(a, grid, st) : launch_scan16<T, D, false, false, true>(a, grid, st);
@@ -601,7 +608,10 @@ hipError_t launch_flat_scan(const ScanArgs& a, int dtype, int D, bool dense, int
   if (dtype == kDtypeI8) return a.half_sqnorm ? hipErrorNotSupported : launch_scan_i8(a, D, dense, grid, st);
   if (dtype != RR_DTYPE_F16 && dtype != RR_DTYPE_BF16) return hipErrorInvalidValue;
 #ifdef RR_DEV_VARIANTS
-  if (dev_scan_handles(a, D, g_scan_variant, g_generic_tall)) return launch_dev_scan(a, dtype, D, dense, grid, st, g_scan_variant, g_generic_tall);
+  if (dev_scan_handles(a, D, g_scan_variant, g_generic_tall)) {
+    if (a.ranges) return hipErrorNotSupported;   // the development kernels have no tile cursor: plain searches only
+    return launch_dev_scan(a, dtype, D, dense, grid, st, g_scan_variant, g_generic_tall);
+  }
 #endif
   const bool f16 = dtype == RR_DTYPE_F16;
   if (half_resident_dim(D) && (int)a.nq < g_wide_min_queries && !a.half_sqnorm)  // 768 < D <= 1536, small batch: 32 resident queries per wave

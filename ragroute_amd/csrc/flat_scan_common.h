@@ -337,7 +337,9 @@ __device__ __forceinline__ float max4v(const f32x4& v) { return max4(v[0], v[1],
 // DEAL: the query blocks are dealt round robin instead (slot qb of wave w = block 4 qb + w: flat_scan16_kernel)
 // qwave: the wave index the lane's QUERIES are derived from, where that is not the wave itself (row-split kernel: two waves share a
 // query quarter; `wave` still names the wave's own compaction scratch)
-template <bool DENSE, int NQB, int QPW = 64, bool INLINE_COMPACT = false, int WAVES = 256 / QPW, bool DEAL = false>
+// SEG: the launch may be a chunk of a segmented search (ScanArgs::ranges / ties_pass are honoured); false compiles the plain
+// search's arithmetic only (no cursor compare per tile, no ties_pass select per refresh: flat_scan16_kernel's plain instantiation)
+template <bool DENSE, int NQB, int QPW = 64, bool INLINE_COMPACT = false, int WAVES = 256 / QPW, bool DEAL = false, bool SEG = true>
 __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& st, f32x4 (&acc)[2][4], uint32_t j, int lane, int wave,
                                                 int qwave = -1) {
   const int col = lane & 15, g = lane >> 4;
@@ -351,7 +353,7 @@ __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& s
     }
     return;
   }
-  if (j >= st.cur.j_end) {   // segmented search only (plain: j_end = ~0); wave-uniform, once per segment and launch: the wave enters
+  if (SEG && j >= st.cur.j_end) {   // segmented search only (plain: j_end = ~0); wave-uniform, once per segment and launch: the wave enters
     // another segment's slice - its valid-row limit and its thresholds (+inf for queries not routed to it) replace the lane's
     const RangeEntry e = cursor_advance(a, st.cur, j);
     st.row_limit = e.row_limit;
@@ -360,7 +362,7 @@ __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& s
     for (int qb = 0; qb < 4; ++qb) qi[qb] = DEAL ? (qb * 4 + qw) * 16 + col : qw * QPW + (qb < NQB ? qb : 0) * 16 + col;
     load_thresholds<NQB>(a, e.seg, qi, st.thr);
   }
-  const uint32_t tile = a.tile_first + j * a.tile_stride + (uint32_t)st.cur.delta;
+  const uint32_t tile = a.tile_first + j * a.tile_stride + (SEG ? (uint32_t)st.cur.delta : 0u);
 #ifndef RR_EPILOGUE_MASKS
 #define RR_EPILOGUE_MASKS 0   // 1: the insertion path branches on wave masks made by the filter instead of re-deriving them per group (measured: headline -0.4 %, config 2 +0.8 %, i.e. noise; off)
 #endif
@@ -424,7 +426,7 @@ __device__ __forceinline__ void tile_epilogue16(const ScanArgs& a, LaneState4& s
         uint64_t* buf = a.cand + (size_t)__builtin_amdgcn_readfirstlane(off);
         const uint64_t kth = INLINE_COMPACT ? wave_compact_inl(buf, scratch, __builtin_amdgcn_readfirstlane(cnt), a.k, lane)
                                             : wave_compact(buf, scratch, __builtin_amdgcn_readfirstlane(cnt), a.k, lane);
-        if (lane == L) { st.cnt[qb] = a.k; st.thr[qb] = a.ties_pass ? next_below(key_score(kth)) : key_score(kth); }
+        if (lane == L) { st.cnt[qb] = a.k; st.thr[qb] = (SEG && a.ties_pass) ? next_below(key_score(kth)) : key_score(kth); }
       }
     }
     // Inlined, the compaction's own global loads are visible to hipcc's waitcnt pass: without a wait IT can see, it treats

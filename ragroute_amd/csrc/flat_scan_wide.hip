@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(512) void flat_scan_wide_rs_kernel(const ScanArgs a
 
 static int wide_pd() {  // RR_WIDE_PD: 0 = the round-1 kernel (one slab in flight), 2 / 3 = query prefetch distance of the deeper pipeline
   static const int v = [] {
-    const char* e = getenv("RR_WIDE_PD");
+    const char* e = tuning_env("RR_WIDE_PD");
     const int x = e ? atoi(e) : 2;
     return (x == 0 || x == 2 || x == 3) ? x : 2;
   }();
@@ -1157,7 +1157,7 @@ static int wide_pd() {  // RR_WIDE_PD: 0 = the round-1 kernel (one slab in fligh
 // search: d = 1024 3.53 vs 3.43 TB/s, 1536 3.61 vs 3.50, 2048 3.74 vs 3.64, 4096 3.74 vs 3.82.  RR_WIDE_WAVES=4|8 forces one.
 static int wide_waves(int D) {
   static const int forced = [] {
-    const char* e = getenv("RR_WIDE_WAVES");
+    const char* e = tuning_env("RR_WIDE_WAVES");
     const int v = e ? atoi(e) : 0;
     return (v == 4 || v == 8) ? v : 0;
   }();
@@ -1168,7 +1168,7 @@ static int wide_waves(int D) {
 // 160 queries 0.605 (8 waves) against 0.59, 192 queries 0.575 -> 0.60, 224 and 256 queries 8 waves (0.54 / 0.51 against 0.505 / 0.50).
 static int wide_waves_for(int D, int nq) {
   const int w = wide_waves(D);
-  static const bool forced = getenv("RR_WIDE_WAVES") != nullptr;
+  static const bool forced = tuning_env("RR_WIDE_WAVES") != nullptr;
   if (forced || w != 8) return w;
   const int nblk = (nq + 15) / 16;
   return (nblk == 9 || nblk == 11 || nblk == 12) ? 4 : 8;
@@ -1179,9 +1179,9 @@ static int wide_waves_for(int D, int nq) {
 // 0.512-0.521, 3072 0.521-0.524 vs 0.510-0.512, 4096 0.525-0.526 vs 0.511-0.513, 8192 0.516-0.517 vs 0.501-0.505; with 208 queries
 // or fewer the kernels that leave query quarters out win (160 queries: 0.61 against 0.52).
 bool scan_wide_rowsplit(int D, int nq, bool l2, int k) {
-  static const bool on = [] { const char* e = getenv("RR_WIDE_RS"); return !(e && atoi(e) == 0) && !getenv("RR_WIDE_WAVES"); }();
-  static const int max_d = [] { const char* e = getenv("RR_WIDE_RS_MAXD"); return e ? atoi(e) : kMaxDim; }();   // (tuning runs)
-  static const int min_q = [] { const char* e = getenv("RR_WIDE_RS_MINQ"); return e ? atoi(e) : 209; }();
+  static const bool on = [] { const char* e = tuning_env("RR_WIDE_RS"); return !(e && atoi(e) == 0) && !tuning_env("RR_WIDE_WAVES"); }();
+  static const int max_d = [] { const char* e = tuning_env("RR_WIDE_RS_MAXD"); return e ? atoi(e) : kMaxDim; }();   // (tuning runs)
+  static const int min_q = [] { const char* e = tuning_env("RR_WIDE_RS_MINQ"); return e ? atoi(e) : 209; }();
   return on && wide_pd() != 0 && !l2 && D > kMaxResidentDim && D <= max_d && nq >= min_q && k <= 128;
 }
 // name of the filter-launch kernel launch_scan_wide_t picks (reported by rr_flat_scan_kernel_name)

@@ -2,8 +2,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace rr {
+
+// Tuning / diagnostic variables (RR_SCAN_VARIANT, RR_WIDE_*, RR_CHUNK_GROWTH, RR_SAMPLE_ROWS, RR_SCAN_TIMELINE, ...) re-route kernels
+// and schedules.  Only development builds (-DRR_DEV_VARIANTS, ragroute_amd/_build.py) honour them: a PRODUCT build reads none, so
+// a stray variable in a service's environment cannot change the kernel under test or in production
+// (tests/test_cabi_exports.py::test_product_library_ignores_tuning_variables).
+inline const char* tuning_env(const char* name) {
+#ifdef RR_DEV_VARIANTS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -28,6 +28,10 @@ for n_segs in (1, 2, 32):
 segs = (S * 2)(S(0, 300, 0, 0, 0), S(256, 10, 0, 1, 0))                                                                            # overlap
 assert L.rr_flat_search_segments(None, 0, 1000, 768, segs, 2, None, 1, 5, None, None, None, 0, None, 64, None) == -1
 assert L.rr_flat_search_segments(None, 0, 1000, 768, segs, 33, None, 1, 5, None, None, None, 0, None, 64, None) == -1
+segs = (S * 1)(S(256, (1 << 63) - 1, 0, 0, 0))                                  # row_begin + n_rows would overflow int64
+assert L.rr_flat_search_segments(None, 0, 1000, 768, segs, 1, None, 1, 5, None, None, None, 0, None, 64, None) == -1
+segs = (S * 1)(S(1 << 62, 10, 0, 0, 0))                                          # row_begin beyond the matrix
+assert L.rr_flat_search_segments(None, 0, 1000, 768, segs, 1, None, 1, 5, None, None, None, 0, None, 64, None) == -1
 assert L.rr_flat_search_segments(None, 0, 1000, 768, None, 1, None, 1, 5, None, None, None, 0, None, 64, None) == -1
 assert L.rr_merge_topk(None, None, 1, 9000, 5, 1, None, None, None) == -2
 assert L.rr_merge_topk_gathered(None, 8, 256 * 32 * 12, 256 * 32 * 4, 1, 256, 32, 32, 1, None, None, None) == -1

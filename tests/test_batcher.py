@@ -81,3 +81,70 @@ def test_batcher_rejects_wrong_result_count():
             await asyncio.gather(*[b.submit(i) for i in range(3)])
         await b.close()
     asyncio.run(go())
+
+
+# ---- two-stage form: window i's reply building overlaps window i+1's search ------------------------------------------
+def test_pipelined_batcher_overlaps_search_and_finish_and_keeps_results_per_request():
+    log = []
+
+    def search(items):
+        log.append(("s0", time.perf_counter()))
+        time.sleep(0.05)
+        log.append(("s1", time.perf_counter()))
+        return list(items)
+
+    def finish(handle):
+        log.append(("f0", time.perf_counter()))
+        time.sleep(0.05)
+        log.append(("f1", time.perf_counter()))
+        return [x * 10 for x in handle]
+
+    async def go():
+        b = QueryBatcher(search=search, finish=finish, max_batch=4, max_wait_ms=1)
+        res = await asyncio.gather(*[b.submit(i) for i in range(12)])
+        await b.close()
+        return res, b
+    res, b = asyncio.run(go())
+    assert res == [i * 10 for i in range(12)]
+    assert b.batches_run == 3 and b.items_run == 12
+    s0 = [t for k, t in log if k == "s0"]
+    f1 = [t for k, t in log if k == "f1"]
+    assert s0[1] < f1[0] and s0[2] < f1[1], "the next window's search must start before the previous window's replies are built"
+    # one search and one finish at a time, windows complete in order
+    spans = sorted((t, k) for k, t in log)
+    assert [k for _, k in spans if k[0] == "s"] == ["s0", "s1"] * 3 and [k for _, k in spans if k[0] == "f"] == ["f0", "f1"] * 3
+    assert b.search_seconds >= 0.14 and b.finish_seconds >= 0.14
+
+
+def test_pipelined_batcher_failures_stay_in_their_window():
+    state = {"s": 0, "f": 0}
+
+    def search(items):
+        state["s"] += 1
+        if state["s"] == 1:
+            raise ValueError("search failed")
+        return list(items)
+
+    def finish(handle):
+        state["f"] += 1
+        if state["f"] == 1:
+            raise KeyError("finish failed")
+        return handle
+
+    async def go():
+        b = QueryBatcher(search=search, finish=finish, max_batch=2, max_wait_ms=20)
+        a = await asyncio.gather(*[b.submit(i) for i in range(2)], return_exceptions=True)
+        c = await asyncio.gather(*[b.submit(i) for i in range(2)], return_exceptions=True)
+        d = await asyncio.gather(*[b.submit(i) for i in range(2)])
+        short = QueryBatcher(search=lambda items: items, finish=lambda h: h[:-1], max_batch=8, max_wait_ms=5)
+        with pytest.raises(RuntimeError):
+            await asyncio.gather(*[short.submit(i) for i in range(3)])
+        await b.close()
+        await short.close()
+        return a, c, d
+    a, c, d = asyncio.run(go())
+    assert all(isinstance(e, ValueError) for e in a) and all(isinstance(e, KeyError) for e in c) and d == [0, 1]
+    with pytest.raises(ValueError):
+        QueryBatcher(search=lambda i: i)
+    with pytest.raises(ValueError):
+        QueryBatcher()

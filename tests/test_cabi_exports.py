@@ -57,6 +57,33 @@ def test_argument_validation_without_gpu():
     assert L.rr_flat_search_workspace_bytes(0) == 0
 
 
+def test_segment_row_counts_cannot_overflow():
+    from ragroute_amd import _lib
+    L, S = _lib.lib(), _lib.SegmentStruct
+    for seg in (S(256, (1 << 63) - 1, 0, 0, 0), S(1 << 62, 10, 0, 0, 0), S(0, 1001, 0, 0, 0)):
+        assert L.rr_flat_search_segments(None, 0, 1000, 768, (S * 1)(seg), 1, None, 1, 5, None, None, None, 0, None, 64, None) == -1
+        assert b"inside the matrix" in L.rr_last_error()
+
+
+def test_product_library_ignores_tuning_variables():
+    """RR_WIDE_* / RR_SCAN_VARIANT / RR_CHUNK_GROWTH re-route kernels and schedules in DEVELOPMENT builds only (rr::tuning_env):
+    with every one of them set, a product library names the same kernels as without."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\nfrom ragroute_amd import _lib\nL = _lib.lib()\n"
+            "print([L.rr_flat_scan_kernel_name(d, q).decode() for d in (768, 1024, 2048, 4096) for q in (1, 100, 160, 208, 256)])" % ROOT)
+    base = {k: v for k, v in os.environ.items() if not k.startswith("RR_")}
+    tuned = dict(base, RR_WIDE_RS="0", RR_WIDE_RS_MAXD="1024", RR_WIDE_RS_MINQ="1", RR_WIDE_WAVES="4", RR_WIDE_PD="0", RR_CHUNK_GROWTH="2",
+                 RR_SCAN_VARIANT="15", RR_GENERIC_TALL="4", RR_WIDE_MIN_QUERIES="1", RR_SAMPLE_ROWS="1024", RR_SCAN_TIMELINE="1")
+    plain = subprocess.run([sys.executable, "-c", code], env=base, capture_output=True, text=True, timeout=120)
+    other = subprocess.run([sys.executable, "-c", code], env=tuned, capture_output=True, text=True, timeout=120)
+    assert plain.returncode == 0 and other.returncode == 0, (plain.stderr[-500:], other.stderr[-500:])
+    assert plain.stdout == other.stdout and "flat_scan_wide_rs_kernel" in plain.stdout
+    src = "".join(open(os.path.join(ROOT, "ragroute_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "ragroute_amd", "csrc"))
+                  if f.endswith((".hip", ".h")) and f != "flat_scan_dev.hip")
+    assert len(re.findall(r"\bgetenv\(", src)) == 1, "every RR_* variable goes through rr::tuning_env (rr_common.h)"
+
+
 def test_library_under_test_is_a_product_build():
     """rr_build_flags(): no -D switch, i.e. neither the development kernels nor the timing-only ablations (which produce wrong
     scores) are compiled in; RR_LIB_OVERRIDE (A/B libraries) must not be set when the suite runs."""

@@ -82,13 +82,17 @@ def plan_mode(dataset, batches, G, whole, with_one):
     emb = W.query_embeddings(fed, B, dev)
     xq, xq_models = W.queries_by_source(fed, emb), W.pack_router_input(dataset, fed, emb, dev)
 
+    results = {}
+
     def run(plan):
         out = []
+        results[len(plan.ranks)] = res_ranks = []
         for r in range(len(plan.ranks)):
             pipe = RetrievalPipeline.from_placement(plan, r, fill_half=W.fill_half, router=router, device=dev)
             step = lambda: pipe.search(xq, k, xq_models=xq_models)   # noqa: E731
             for _ in range(3):
-                step()
+                D, I = step()
+            res_ranks.append((D.clone(), I.clone()))
             ms = timed_events(step, batches)
             out.append({"rank": r, "measured_ms": round(ms[len(ms) // 2], 4), "p90_ms": round(ms[(len(ms) * 9) // 10], 4),
                         "predicted_ms": round(plan.predicted_ms[r], 4),
@@ -112,6 +116,13 @@ def plan_mode(dataset, batches, G, whole, with_one):
            "exchange_bytes_per_rank": plan.slots * B * k * 12, "ranks": ranks}
     if with_one:
         one = run(P.plan(fed, 1))[0]
+        # the G ranks' local results merged (rerank.merge_topk = what the exchange + merge do) against the one-GPU search of the
+        # same federation: the row slices must not change a single id or score
+        from ragroute_amd.rerank import merge_topk
+        Dm, Im = merge_topk(torch.cat([d for d, _ in results[G]], 1), torch.cat([i for _, i in results[G]], 1), k, True)
+        D1, I1 = results[1][0]
+        res["merged_G_ranks_equal_one_gpu"] = {"ids": bool(torch.equal(Im, I1)), "scores": bool(torch.equal(Dm, D1)),
+                                               "queries": int(I1.shape[0]), "k": k, "ids_checksum": int(I1.sum())}
         res["one_gpu_ms"] = one["measured_ms"]
         res["one_gpu_units"] = len(one["units"])
         res["predicted_speedup_at_G"] = round(one["measured_ms"] / (max(meas) + res["merge_of_G_ranks_ms"]), 3)
