@@ -19,6 +19,11 @@ LLVM_BIN = os.environ.get("RR_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 
 # kernels whose accumulators live in hard-wired AGPRs named only inside asm text
 FIXED_AGPR_KERNELS = ("flat_scan_wide",)   # flat_scan_wide_kernel, _pd_kernel, wide8_kernel
+# Scalar-register pressure tripwire for the hand-scheduled kernels: the largest .sgpr_spill_count per kernel family as of round 4
+# (only the L2 four-block instances of the 4-wave kernel spill, 2 SGPRs, outside the counted-wait step).  Spilled SGPRs go to
+# lanes of a compiler-owned VGPR (v_writelane / v_readlane), which is correct but costs issue slots inside a loop whose waits
+# are counted by hand: a count above these is a build failure, to be looked at, not waved through.
+SGPR_SPILL_MAX = {"flat_scan_wide_pd_kernel": 2, "flat_scan_wide8_kernel": 0, "flat_scan_wide_rs_kernel": 0, "flat_scan_wide_kernel": 0}
 
 
 PRODUCT_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"]   # what rr_build_flags() of a product library reports
@@ -65,7 +70,11 @@ def check_isa(obj_path):
             continue
         seen += 1
         # (.sgpr_spill_count may be non-zero: scalar spills go to lanes of a VGPR the compiler owns - never to the hard-wired AGPRs,
-        # and never to memory while private_segment_fixed_size stays 0)
+        # and never to memory while private_segment_fixed_size stays 0 - but not above the recorded bound of the kernel family)
+        m = re.search(r"\.sgpr_spill_count:\s+(\d+)", block)
+        family = max((f for f in SGPR_SPILL_MAX if f in name.group(1)), key=len, default=None)
+        if m and family is not None and int(m.group(1)) > SGPR_SPILL_MAX[family]:
+            problems.append(f"{name.group(1)}: .sgpr_spill_count = {m.group(1)} > {SGPR_SPILL_MAX[family]} (SGPR_SPILL_MAX: scalar pressure grew in a hand-scheduled kernel)")
         for key in (".private_segment_fixed_size", ".vgpr_spill_count"):
             m = re.search(re.escape(key) + r":\s+(\d+)", block)
             if m and int(m.group(1)) != 0:
@@ -143,15 +152,18 @@ def build(force=False, verbose=False):
     lib_path = LIB_PATH.replace(".so", suffix + ".so") if suffix else LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = _flags()
-    os.makedirs(OBJ_DIR, exist_ok=True)
+    # objects of a suffixed (development / A/B) library live in their own directory: "flat_scan" + "_dev" must not meet the
+    # product object of flat_scan_dev.hip
+    obj_dir = os.path.join(OBJ_DIR, suffix.strip("_")) if suffix else OBJ_DIR
+    os.makedirs(obj_dir, exist_ok=True)
     headers = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(PKG, "..", "include", "ragroute_hip.h")]
     hdr_time = max(os.path.getmtime(h) for h in headers)
-    stamp = os.path.join(OBJ_DIR, f"flags{suffix}.txt")
+    stamp = os.path.join(obj_dir, "flags.txt")
     flags_changed = not os.path.exists(stamp) or open(stamp).read() != " ".join(flags)
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ_DIR, s.replace(".hip", suffix + ".o"))
+        obj = os.path.join(obj_dir, s.replace(".hip", ".o"))
         stale = force or flags_changed or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time)
         jobs.append((src, obj, stale))
     todo = [(src, obj) for src, obj, stale in jobs if stale]
@@ -159,14 +171,14 @@ def build(force=False, verbose=False):
         return lib_path
 
     # rr_build_flags(): capi.hip includes the flag string as a C literal
-    inc = os.path.join(OBJ_DIR, "rr_build_flags.inc")
+    inc = os.path.join(obj_dir, "rr_build_flags.inc")
     literal = '"' + " ".join(flags).replace("\\", "\\\\").replace('"', '\\"') + '"\n'
     if not os.path.exists(inc) or open(inc).read() != literal:
         open(inc, "w").write(literal)
 
     def compile_one(job):
         src, obj = job
-        res = _run([hipcc] + flags + ["-c", src, "-o", obj], f"hipcc -c {os.path.basename(src)}")
+        res = _run([hipcc] + flags + [f"-I{obj_dir}", "-c", src, "-o", obj], f"hipcc -c {os.path.basename(src)}")
         return res.stderr
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as pool:
@@ -175,7 +187,7 @@ def build(force=False, verbose=False):
                 print(err)
     open(stamp, "w").write(" ".join(flags))
     if not os.environ.get("RR_SKIP_ISA_CHECK"):   # diagnostic builds only
-        check_isa(os.path.join(OBJ_DIR, "flat_scan_wide" + suffix + ".o"))
+        check_isa(os.path.join(obj_dir, "flat_scan_wide.o"))
     _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + [o for _, o, _ in jobs], "hipcc -shared")
     return lib_path
 
@@ -190,7 +202,7 @@ def build_asan_host(out_dir=None):
     obj = os.path.join(out_dir, "capi_asan.o")
     lib_path = os.path.join(out_dir, "libragroute_hip_asan.so")
     _run([hipcc] + PRODUCT_FLAGS + ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan",
-                                    "-c", os.path.join(CSRC, "capi.hip"), "-o", obj], "hipcc -fsanitize=address -c capi.hip")
+                                    f"-I{OBJ_DIR}", "-c", os.path.join(CSRC, "capi.hip"), "-o", obj], "hipcc -fsanitize=address -c capi.hip")
     others = [os.path.join(OBJ_DIR, s.replace(".hip", ".o")) for s in SOURCES if s != "capi.hip"]
     _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address", "-shared-libsan", "-o", lib_path, obj] + others,
          "hipcc -shared (asan)")

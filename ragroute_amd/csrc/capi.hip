@@ -109,8 +109,8 @@ struct Workspace {
 Workspace carve(char* base, int k, int grid, int dim) {
   using namespace rr;
   const int cap = cand_cap_for_k(k);
-  // candidate buffers per (workgroup, query): 4 lane quarters; the row-split wide-row kernel (dim > 768, k <= 128) uses 8
-  const int bpw = (k <= 128 && dim > kMaxResidentDim) ? 8 : 4;
+  // candidate buffers per (workgroup, query): 4 lane quarters; the row-split wide-row kernel (dim > 768) uses 8
+  const int bpw = dim > kMaxResidentDim ? 8 : 4;
   Workspace w;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return base ? base + o : (char*)nullptr; };
@@ -134,10 +134,10 @@ Workspace carve(char* base, int k, int grid, int dim) {
 
 }  // namespace
 
-// The compile flags of this library, written by ragroute_amd/_build.py next to the objects before it compiles this unit.
-#if __has_include("build/rr_build_flags.inc")
+// The compile flags of this library, written by ragroute_amd/_build.py next to the objects (its -I directory) before it compiles this unit.
+#if __has_include("rr_build_flags.inc")
 const char kBuildFlags[] =
-#include "build/rr_build_flags.inc"
+#include "rr_build_flags.inc"
     ;
 #else
 const char kBuildFlags[] = "unknown (not built by ragroute_amd/_build.py)";

@@ -2,10 +2,10 @@
 // Replaces the arithmetic inside `index.search(query_embed, k)` (reference ragroute/data_source.py:158,186,203) for
 // FeB4RAG's 1024- and 4096-wide encoders (config.py:45-57, 92-96).  Split from flat_scan.hip (the query-resident kernels).
 // Kernels in this file (launch_scan_wide_t picks one):
-//   flat_scan_wide_rs_kernel  209 ... 256 queries, inner product, k <= 128 (round 3): 8 waves = 2 row halves x 4 query quarters, the
-//                             query columns of a K step DMA'd into LDS once per CU
-//   flat_scan_wide8_kernel    d <= 2048, up to 208 queries (and the L2 metric): 8 waves, queries streamed into registers
-//   flat_scan_wide_pd_kernel  d > 2048 up to 208 queries, 9 / 11 / 12 query blocks at d <= 2048, every dense (sample) launch: 4 waves
+//   flat_scan_wide_rs_kernel  209 ... 256 queries (193 ... 256 at d > 2048), either metric, any k (round 3; L2 / k > 128 / 193+ round 4):
+//                             8 waves = 2 row halves x 4 query quarters, the query columns of a K step DMA'd into LDS once per CU
+//   flat_scan_wide8_kernel    d <= 2048, up to 208 queries: 8 waves, queries streamed into registers
+//   flat_scan_wide_pd_kernel  d > 2048 up to 192 queries, 9 / 11 / 12 query blocks at d <= 2048, every dense (sample) launch: 4 waves
 //   flat_scan_wide_kernel     round 1's form (RR_WIDE_PD=0, A/B runs)
 #include "flat_scan_common.h"
 
@@ -948,7 +948,9 @@ __global__ __launch_bounds__(512) void flat_scan_wide8_kernel(const ScanArgs a, 
 // Timing-only ablations priced it at +5 ... 7 % (profiles/r03/wide8_rowsplit_pricing.json).  Rings: corpus 3 slots (two steps ahead:
 // HBM latency), queries 2 slots (one step ahead: they come from L2) = all 160 KB of LDS.  Two waves share each query, so a
 // workgroup owns 8 candidate buffers per query (row half x lane quarter).
-template <typename T>
+// L2 = true (round 4): ranks by q.x - |x|^2/2 like the other kernels' L2 forms - the epilogue subtracts the rows' half squared norms
+// (a.half_sqnorm) from the accumulators before the filter; an L2 search is never segmented.
+template <typename T, bool L2 = false>
 __global__ __launch_bounds__(512) void flat_scan_wide_rs_kernel(const ScanArgs a, const int D) {
   typedef typename Mfma<T>::frag frag;
   constexpr int NT = 8;                    // 32-row tiles per group (256 rows)
@@ -1132,6 +1134,20 @@ __global__ __launch_bounds__(512) void flat_scan_wide_rs_kernel(const ScanArgs a
           e[0][qb] = read_acc_fixed128<4 * ((2 * t) * 4 + qb)>();
           e[1][qb] = read_acc_fixed128<4 * ((2 * t + 1) * 4 + qb)>();
         });
+        if (L2) {
+          const uint32_t r0 = (a.tile_first + j * a.tile_stride) * kTileRows + 4 * g;
+          f32x4 h0, h1;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            h0[i] = a.half_sqnorm[r0 + i < a.n_rows ? r0 + i : a.n_rows - 1];
+            h1[i] = a.half_sqnorm[r0 + 16 + i < a.n_rows ? r0 + 16 + i : a.n_rows - 1];
+          }
+#pragma unroll
+          for (int qb = 0; qb < 4; ++qb) {
+            e[0][qb] -= h0;
+            e[1][qb] -= h1;
+          }
+        }
         tile_epilogue16<false, 4, 64, true, 8>(a, st, e, j, lane, wave, qq);
       }
     });
@@ -1174,15 +1190,22 @@ static int wide_waves_for(int D, int nq) {
   return (nblk == 9 || nblk == 11 || nblk == 12) ? 4 : 8;
 }
 
-// 209 ... 256 queries at d > 768, inner product, k <= 128: the row-split kernel (RR_WIDE_RS=0 / RR_WIDE_WAVES switch it off).
+// 209 ... 256 queries at d > 768, 193 ... 256 at d > 2048 (round 4: either metric, any k; a workgroup owns 8 candidate buffers per query there): the row-split
+// kernel (development builds: RR_WIDE_RS=0 / RR_WIDE_WAVES switch it off, RR_WIDE_RS_MAXK / _L2 restore round 3's limits for A/B runs).
 // Measured against the kernels it replaces (scan launches, 256 queries): d = 1024 0.522-0.529 vs 0.510-0.515, 2048 0.527-0.530 vs
 // 0.512-0.521, 3072 0.521-0.524 vs 0.510-0.512, 4096 0.525-0.526 vs 0.511-0.513, 8192 0.516-0.517 vs 0.501-0.505; with 208 queries
 // or fewer the kernels that leave query quarters out win (160 queries: 0.61 against 0.52).
 bool scan_wide_rowsplit(int D, int nq, bool l2, int k) {
   static const bool on = [] { const char* e = tuning_env("RR_WIDE_RS"); return !(e && atoi(e) == 0) && !tuning_env("RR_WIDE_WAVES"); }();
   static const int max_d = [] { const char* e = tuning_env("RR_WIDE_RS_MAXD"); return e ? atoi(e) : kMaxDim; }();   // (tuning runs)
-  static const int min_q = [] { const char* e = tuning_env("RR_WIDE_RS_MINQ"); return e ? atoi(e) : 209; }();
-  return on && wide_pd() != 0 && !l2 && D > kMaxResidentDim && D <= max_d && nq >= min_q && k <= 128;
+  // fewest queries it takes: 209 at d <= 2048 (13 blocks run as well or better on the 8-wave kernel: 200 queries 0.524 / 0.531 against
+  // 0.525-0.530 / 0.527-0.537 at d = 1024 / 2048, and its compaction has half the buffers), 193 above 2048, where the alternative is
+  // the 4-wave kernel (193 / 200 / 208 queries at d = 4096: 0.530-0.534 against 0.509-0.512; profiles/r04/rowsplit_widening.json)
+  static const int min_q_env = [] { const char* e = tuning_env("RR_WIDE_RS_MINQ"); return e ? atoi(e) : 0; }();
+  const int min_q = min_q_env ? min_q_env : (D > 2048 ? 193 : 209);
+  static const int max_k = [] { const char* e = tuning_env("RR_WIDE_RS_MAXK"); return e ? atoi(e) : kMaxK; }();
+  static const bool with_l2 = [] { const char* e = tuning_env("RR_WIDE_RS_L2"); return !(e && atoi(e) == 0); }();
+  return on && wide_pd() != 0 && (!l2 || with_l2) && D > kMaxResidentDim && D <= max_d && nq >= min_q && k <= max_k;
 }
 // name of the filter-launch kernel launch_scan_wide_t picks (reported by rr_flat_scan_kernel_name)
 const char* scan_wide_kernel_name(int D, int nq) {
@@ -1222,10 +1245,17 @@ static hipError_t launch_scan_wide_t(const ScanArgs& a, int D, bool dense, int g
   }
   if (!dense && scan_wide_rowsplit(D, (int)a.nq, l2, a.k)) {
     const size_t lds_rs = (size_t)5 * 8 * 4096;   // 3 corpus + 2 query slots of 32 KB: all 160 KB
-    hipError_t ers = hipFuncSetAttribute((const void*)flat_scan_wide_rs_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs);
-    if (ers != hipSuccess) return ers;
-    hipLaunchKernelGGL((flat_scan_wide_rs_kernel<T>), dim3(grid), dim3(512), lds_rs, st, a, D);
-    return hipGetLastError();
+    if (l2 && a.ranges) return hipErrorNotSupported;
+#define RR_LAUNCH_RS(...)                                                                                            \
+  {                                                                                                                  \
+    hipError_t ers = hipFuncSetAttribute((const void*)__VA_ARGS__, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs); \
+    if (ers != hipSuccess) return ers;                                                                               \
+    hipLaunchKernelGGL((__VA_ARGS__), dim3(grid), dim3(512), lds_rs, st, a, D);                                     \
+    return hipGetLastError();                                                                                        \
+  }
+    if (l2) RR_LAUNCH_RS(flat_scan_wide_rs_kernel<T, true>)
+    RR_LAUNCH_RS(flat_scan_wide_rs_kernel<T, false>)
+#undef RR_LAUNCH_RS
   }
   if (!dense && pd != 0 && wide_waves_for(D, (int)a.nq) == 8) {
     hipError_t e8;

@@ -11,7 +11,7 @@ Everything is enqueued on the current stream; nothing synchronises with the host
 
 The reference's counterpart is the fan-out / gather / concat / rerank of http_server.py:198-209, 227-257, 280-293: one
 message per selected source, replies collected in arrival order, flat candidate lists merged by score."""
-from .sharded import SHARD_SHIFT, alloc_packed, exchange_packed, max_over_ranks, merge_gathered
+from .sharded import SHARD_SHIFT, alloc_gathered, alloc_packed, exchange_packed, max_over_ranks, merge_gathered
 
 
 class RetrievalPipeline:
@@ -150,6 +150,7 @@ class RetrievalPipeline:
             if self.slots == 1:
                 D, I = D[None], I[None]
             self._packed = {key: (buf, D, I)}
+            self._gathered = alloc_gathered(buf, self.group)     # the exchange's destination, reused by every search of this (B, k)
         return self._packed[key]
 
     def search(self, xq, k, xq_models=None):
@@ -178,11 +179,11 @@ class RetrievalPipeline:
                 idx.search_prepared(idx.prepare_queries(q), k, id_offset=id_offset, out=(D[slot], I[slot]),
                                     route_mask=None if mask is None else mask[:, sids[0]])
         if self.stage_events is None:
-            out = exchange_packed(buf, self.group)                       # C1: the ONE collective
+            out = exchange_packed(buf, self.group, self._gathered)       # C1: the ONE collective
             return merge_gathered(out, B, k, self.slots, k, True)        # K4, reading the gathered buffer where it lies
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
-        out = exchange_packed(buf, self.group)
+        out = exchange_packed(buf, self.group, self._gathered)
         e1.record()
         res = merge_gathered(out, B, k, self.slots, k, True)
         e2.record()

@@ -2,8 +2,9 @@
 
 `rerank_medrag` / `rerank_wikipedia` are HOST functions, as in the reference (its aiohttp front-end calls them on Python
 lists of <= S*k floats, http_server.py:288-293; `north_star`: "host-side rerank merge"): numpy, no HIP context needed.  They
-use the total order the device merge defines (f32 compare, earlier candidate wins a tie — numpy's argsort leaves tie order
-unspecified, rerank.py:5,30).  `rerank_feb4rag` orders by ground-truth qrels, not by scores (rerank.py:12-25): a host
+compare the scores AS GIVEN (float64, what numpy makes of the reference's Python list: rerank.py:5, 30); the earlier candidate
+wins a tie (numpy's argsort leaves tie order unspecified).  For scores that came from float32 — every score a data source
+returns (faiss D is f32, data_source.py:187) — this is the total order the device merge defines.  `rerank_feb4rag` orders by ground-truth qrels, not by scores (rerank.py:12-25): a host
 dictionary sort, kept as such.
 `merge_topk` (C ABI `rr_merge_topk`, csrc/select.hip) is the batched DEVICE form, used where the candidates already are on
 the device: after the multi-GPU candidate all-gather (sharded.py, pipeline.py)."""
@@ -45,10 +46,11 @@ def merge_topk(D, I, k, descending=True):
 def _rerank_by_score(docs, scores, k, descending):
     """The reference sorts the float64 list with numpy on the HOST (rerank.py:5, 30; called from the aiohttp front-end,
     http_server.py:288-293), and so does this: a <= 128-element sort needs no HIP context in the front-end process.
-    The order is the one `rr_merge_topk` defines, restated in numpy: scores are compared as float32 (what the data sources
-    return: faiss D is f32, data_source.py:187), candidate position is the tie-break (earlier first; numpy's default sort
-    leaves ties unspecified), and NaN scores are placed where numpy's argsort puts them — at the END of the ascending order:
-    `[::-1]` therefore ranks them FIRST for rerank_medrag, rerank_wikipedia keeps them last."""
+    Scores are compared as given (float64, like np.argsort on the reference's list; two scores that differ only beyond float32
+    keep the reference's order — tests/golden/rerank.json "f64_cases"), candidate position is the tie-break (earlier first;
+    numpy's default sort leaves ties unspecified), and NaN scores are placed where numpy's argsort puts them — at the END of the
+    ascending order: `[::-1]` therefore ranks them FIRST for rerank_medrag, rerank_wikipedia keeps them last.  On float32-born
+    scores this is exactly `rr_merge_topk`'s order."""
     n = len(scores)
     if n == 0:
         return [], []
@@ -56,12 +58,12 @@ def _rerank_by_score(docs, scores, k, descending):
         raise ValueError("docs and scores must have the same length")
     if k <= 0:
         return [], []
-    s32 = np.asarray(scores, np.float64).astype(np.float32)
-    nan = np.isnan(s32)
+    s64 = np.asarray(scores, np.float64)
+    nan = np.isnan(s64)
     nan_pos = np.flatnonzero(nan)
     valid = np.flatnonzero(~nan)
-    v = s32[valid]
-    ranked = valid[np.lexsort((valid, -v if descending else v))]      # IEEE f32 compare (-0.0 == 0.0); the earlier candidate wins a tie
+    v = s64[valid]
+    ranked = valid[np.lexsort((valid, -v if descending else v))]      # IEEE compare (-0.0 == 0.0); the earlier candidate wins a tie
     order = (list(nan_pos[::-1]) + list(ranked)) if descending else (list(ranked) + list(nan_pos))
     order = [int(i) for i in order[:k]]
     return [docs[i] for i in order], [scores[i] for i in order]

@@ -70,19 +70,31 @@ def packed_layout(B, k, slots=1):
     return nD, nD + pad, nD + pad + slots * B * k * 8
 
 
-def exchange_packed(buf, group=None):
+def exchange_packed(buf, group=None, out=None):
     """THE collective of the path: all_gather of every rank's packed candidate buffer -> uint8 [world, bytes per rank], left
-    exactly as the collective wrote it (`merge_gathered` reads it in place).  One rank: a view of `buf`, nothing is copied."""
+    exactly as the collective wrote it (`merge_gathered` reads it in place).  One rank: a view of `buf`, nothing is copied.
+    out: optional uint8 tensor of world x buf.numel() bytes on buf's device to gather into (the callers keep one per (B, k):
+    the merge that follows writes fresh result tensors, so the gathered buffer is free again when the next search's collective
+    is enqueued behind it on the stream)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return buf.view(1, buf.numel())
+    if out is None or out.numel() != world * buf.numel() or out.device != buf.device:
+        out = torch.empty(world * buf.numel(), dtype=torch.uint8, device=buf.device)
+    out = out.view(-1)
     if buf.is_cuda and dist.get_backend(group) == "gloo":  # rehearsal on one box: stage through the host
-        out = torch.empty(world * buf.numel(), dtype=torch.uint8)
-        dist.all_gather_into_tensor(out, buf.cpu(), group=group)
-        return out.to(buf.device).view(world, buf.numel())
-    out = torch.empty(world * buf.numel(), dtype=torch.uint8, device=buf.device)
+        host = torch.empty(world * buf.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(host, buf.cpu(), group=group)
+        out.copy_(host)
+        return out.view(world, buf.numel())
     dist.all_gather_into_tensor(out, buf, group=group)
     return out.view(world, buf.numel())
+
+
+def alloc_gathered(buf, group=None):
+    """The reusable destination of exchange_packed for this packed buffer (None on one rank)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    return None if world == 1 else torch.empty(world * buf.numel(), dtype=torch.uint8, device=buf.device)
 
 
 def unpack_gathered(out, B, k, slots=1):
@@ -142,6 +154,7 @@ class ShardedFlatSearch:
         self.group = group
         self.slots = slots
         self._packed = {}
+        self._gathered = None
 
     def local_candidates(self, xq_half, k, route_mask=None):
         """Scan every local shard into this rank's packed buffer; returns (buf, D [slots,B,k], I [slots,B,k]) with global ids.
@@ -152,6 +165,7 @@ class ShardedFlatSearch:
         if (B, k) not in self._packed:
             buf, D, I = alloc_packed(B, k, xq_half.device, self.slots)
             self._packed = {(B, k): (buf, D[None], I[None]) if self.slots == 1 else (buf, D, I)}
+            self._gathered = alloc_gathered(buf, self.group)
         buf, D, I = self._packed[(B, k)]
         for slot, (idx, sid) in enumerate(zip(self.shards, self.shard_ids)):
             idx.search_prepared(xq_half, k, id_offset=sid << SHARD_SHIFT, out=(D[slot], I[slot]),
@@ -161,7 +175,7 @@ class ShardedFlatSearch:
     def search(self, xq_half, k, route_mask=None):
         """Full federated step on device: local scans -> ONE all_gather -> merge.  Every rank gets the result."""
         buf, _, _ = self.local_candidates(xq_half, k, route_mask)
-        out = exchange_packed(buf, self.group)
+        out = exchange_packed(buf, self.group, self._gathered)
         # always through the merge: it writes fresh tensors (the packed buffer is reused by the next search, so returning
         # views of it would let search N+1 overwrite what the caller still holds of search N)
         return merge_gathered(out, xq_half.shape[0], k, self.slots, k, True)

@@ -56,6 +56,21 @@ def golden_rerank():
         wd, ws = R.rerank_wikipedia(docs, scores, k)
         cases.append({"docs": docs, "scores": scores, "k": k, "medrag": [md, [float(s) for s in ms]],
                       "wikipedia": [wd, [float(s) for s in ws]]})
+    # scores that differ only BEYOND float32 (the reference sorts the float64 list as given, rerank.py:5, 30): tie-free in f64,
+    # pairwise equal once rounded to f32
+    f64_cases = []
+    for n, k in [(64, 16), (10, 10), (33, 5)]:
+        base = [float(np.float32(x)) for x in rng.permutation(n * 4)[: n // 2 + 1] / 7.0 - 3.0]
+        scores = []
+        for i in range(n):
+            scores.append(base[i // 2] * (1.0 + (1e-12 if i % 2 else 0.0)) + (3e-13 if i % 2 else 0.0))
+        order = rng.permutation(n)
+        scores = [scores[i] for i in order]
+        assert len(set(scores)) == n and len({float(np.float32(s)) for s in scores}) < n
+        docs = [f"doc{i}" for i in range(n)]
+        md, ms = R.rerank_medrag(docs, scores, k)
+        wd, ws = R.rerank_wikipedia(docs, scores, k)
+        f64_cases.append({"docs": docs, "scores": scores, "k": k, "medrag": [md, [float(s) for s in ms]], "wikipedia": [wd, [float(s) for s in ws]]})
     # ties: only the score multiset is defined by the reference (numpy's argsort order is not)
     tie_scores = [0.1, 0.9, 0.5, 0.9, 0.3, 0.2, 0.7, 0.5]
     md, ms = R.rerank_medrag(list("abcdefgh"), tie_scores, 4)
@@ -67,7 +82,7 @@ def golden_rerank():
         docs = [f"text of {i}" for i in ids]
         od, oi = R.rerank_feb4rag(ids, docs, qid, k, {q: [tuple(x) for x in v] for q, v in rel.items()})
         feb.append({"ids": ids, "docs": docs, "query_id": qid, "k": k, "out_docs": od, "out_ids": oi})
-    json.dump({"cases": cases, "ties": ties, "feb4rag": {"relevance": rel, "cases": feb}},
+    json.dump({"cases": cases, "f64_cases": f64_cases, "ties": ties, "feb4rag": {"relevance": rel, "cases": feb}},
               open(os.path.join(HERE, "rerank.json"), "w"), indent=1)
 
 

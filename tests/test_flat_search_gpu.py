@@ -186,7 +186,9 @@ def test_randomised_shapes(gpu):
 
 
 @pytest.mark.parametrize("n,nq,k,d", [(5000, 40, 10, 768), (90_000, 256, 32, 768), (30_000, 7, 100, 200), (33, 3, 50, 128),
-                                      (40_000, 200, 10, 1024), (40_000, 5, 10, 1024), (20_000, 9, 10, 2048), (300, 3, 10, 4096)])
+                                      (40_000, 200, 10, 1024), (40_000, 5, 10, 1024), (20_000, 9, 10, 2048), (300, 3, 10, 4096),
+                                      # 209 ... 256 queries on wide rows: the row-split kernel's L2 form (round 4), incl. a ragged last tile
+                                      (40_000, 256, 10, 1024), (33_333, 209, 32, 2048), (20_011, 256, 100, 4096), (50_000, 300, 10, 1536)])
 def test_l2_metric_bit_exact_on_integer_data(gpu, n, nq, k, d):
     """Squared-L2 flat search (faiss.IndexFlatL2 contract): nearest first, ties by ascending id, (+inf,-1) padding."""
     from oracle import oracle as O
@@ -298,7 +300,9 @@ def test_wide_rows_adversarial(gpu, d, nq):
     assert np.array_equal(I, Iref) and np.array_equal(D, Dref)
 
 
-@pytest.mark.parametrize("d,n,nq,k", [(1024, 60_000, 200, 500), (2048, 40_000, 256, 100), (4096, 30_000, 256, 300), (1536, 50_000, 129, 1024)])
+@pytest.mark.parametrize("d,n,nq,k", [(1024, 60_000, 200, 500), (2048, 40_000, 256, 100), (4096, 30_000, 256, 300), (1536, 50_000, 129, 1024),
+                                      # row-split kernel beyond k = 128 (round 4: 8 candidate buffers per workgroup at every k)
+                                      (2048, 40_000, 256, 300), (1024, 70_000, 240, 1024), (4096, 30_000, 209, 129)])
 def test_wide_rows_large_k(gpu, d, n, nq, k):
     """Large k through the wide-row kernels (two waves per SIMD up to d = 2048, one above): candidate buffers of 2k entries per
     lane, compactions inlined in the kernel, several chunks.  Integer data: ids and scores bit for bit."""

@@ -104,9 +104,15 @@ def test_no_read_past_the_end_segmented_search(gpu):
     _in_child("import torch, tests.test_guard_pages_gpu as t; t._run_segmented(torch.device('cuda:0')); print('ok')")
 
 
-@pytest.mark.parametrize("waves", ["4", "8"])
-def test_no_read_past_the_end_both_wide_row_flavours(gpu, waves):
-    """RR_WIDE_WAVES is read once per process: the forced flavours run in a child process."""
+def test_no_read_past_the_end_every_wide_row_kernel(gpu):
+    """Query counts that reach every wide-row kernel under the product dispatch (a product library ignores RR_WIDE_WAVES, which forced
+    the flavours in rounds 2-3): 9 / 11 / 12 query blocks and d > 2048 up to 192 queries -> 4 waves (flat_scan_wide_pd_kernel), other
+    counts up to 208 at d <= 2048 -> 8 waves (flat_scan_wide8_kernel), 209 ... 256 (193 ... 256 at d > 2048) -> the row-split kernel;
+    17 ... 128 at d <= 1536 the half-resident kernel."""
+    from ragroute_amd import _lib
+    L = _lib.lib()
+    names = {L.rr_flat_scan_kernel_name(d, q).decode() for d, q in ((1024, 144), (1024, 200), (1024, 256), (1024, 100), (2048, 160), (2048, 176), (4096, 180), (4096, 200))}
+    assert names == {"flat_scan_wide_pd_kernel", "flat_scan_wide8_kernel", "flat_scan_wide_rs_kernel", "flat_scan16h_kernel"}, names
     _in_child("import torch, tests.test_guard_pages_gpu as t; "
-              "t._run_cases(torch.device('cuda:0'), [(1024, 40_000, (200, 256)), (2048, 30_000, (1, 4, 17, 256)), (4096, 12_345, (1, 5, 256))]); print('ok')",
-              {"RR_WIDE_WAVES": waves})
+              "t._run_cases(torch.device('cuda:0'), [(1024, 40_000, (100, 144, 200, 209, 256)), (2048, 30_000, (1, 4, 17, 160, 176, 208, 256)), "
+              "(4096, 12_345, (1, 5, 180, 193, 200, 256))]); print('ok')")

@@ -53,8 +53,11 @@ CASES = [
     (768, [300, 5, 4100, 77], 256, 32),                  # under 8192 rows in total: the dense path
     (768, [9_000, 31, 257, 120_000, 1], 256, 10),        # a one-row source; 256 queries
     (1024, [30_000, 3_633, 8_674, 25_000], 100, 10),     # feb4rag's UAE-Large-V1 group, <= 128 queries: half-resident kernel
-    (1024, [30_000, 3_633, 8_674, 25_000], 256, 10),     # ... 256 queries: 8-wave wide-row kernel
-    (4096, [9_000, 2_000, 14_000], 256, 10),             # wide rows: 4-wave kernel, K rotation per 256-row group
+    (1024, [30_000, 3_633, 8_674, 25_000], 256, 10),     # ... 256 queries: row-split wide-row kernel (flat_scan_wide_rs_kernel)
+    (1024, [30_000, 3_633, 8_674, 25_000], 200, 10),     # ... 200 queries: 8-wave wide-row kernel
+    (4096, [9_000, 2_000, 14_000], 256, 10),             # wide rows: row-split kernel, K rotation per 256-row group
+    (4096, [9_000, 2_000, 14_000], 180, 10),             # ... 180 queries: 4-wave kernel (flat_scan_wide_pd_kernel)
+    (2048, [9_000, 2_000, 14_000], 256, 300),            # row-split kernel with k beyond one candidate-buffer generation (round 4: any k)
     (128, [50_000, 50_000], 37, 100),
     (768, [20_000, 5_000, 9_000], 8, 300),               # k beyond one candidate-buffer generation
     (256, [700 + 13 * i for i in range(32)], 40, 10),   # RR_MAX_SEGMENTS sources
@@ -233,10 +236,11 @@ def test_torch_ops_reach_the_segmented_search_and_the_in_place_merge(gpu):
 
 
 def test_workspace_size_by_width(gpu):
-    """Rows up to 768 wide need 4 candidate buffers per workgroup and query, wider rows 8 (the row-split kernel, k <= 128):
-    rr_flat_search_workspace_bytes_for sizes for one width, rr_flat_search_workspace_bytes for any."""
+    """Rows up to 768 wide need 4 candidate buffers per workgroup and query, wider rows 8 (the row-split kernel; since round 4 at
+    every k): rr_flat_search_workspace_bytes_for sizes for one width, rr_flat_search_workspace_bytes for any."""
     from ragroute_amd import _lib
     L = _lib.lib()
     a, b, c = L.rr_flat_search_workspace_bytes_for(32, 768), L.rr_flat_search_workspace_bytes_for(32, 1024), L.rr_flat_search_workspace_bytes(32)
     assert 0 < a < b == c
-    assert L.rr_flat_search_workspace_bytes_for(32, 1000) == 0 and L.rr_flat_search_workspace_bytes_for(300, 1024) == L.rr_flat_search_workspace_bytes_for(300, 768)
+    assert L.rr_flat_search_workspace_bytes_for(32, 1000) == 0
+    assert L.rr_flat_search_workspace_bytes_for(300, 768) < L.rr_flat_search_workspace_bytes_for(300, 1024) == L.rr_flat_search_workspace_bytes(300)

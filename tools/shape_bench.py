@@ -1,6 +1,6 @@
 """Bench-style JSON line for one flat-search shape (development / profiles; bench.py is the contract for the headline).
 
-    python tools/shape_bench.py ROWS DIM [BATCH] [K] [DTYPE] [ITERS]
+    python tools/shape_bench.py ROWS DIM [BATCH] [K] [DTYPE] [ITERS] [ip|l2]
 
 Synthetic N(0,1)/sqrt(d) corpus generated on device, queries resident in HBM; times ITERS back-to-back searches with one
 HIP-event pair per search (median / p10 / p90) and the scan launches with the library's own HIP events (rr_profile_*), then
@@ -24,9 +24,10 @@ def main():
     k = int(sys.argv[4]) if len(sys.argv) > 4 else 32
     dtype = sys.argv[5] if len(sys.argv) > 5 else "fp16"
     iters = int(sys.argv[6]) if len(sys.argv) > 6 else 50
+    metric = sys.argv[7] if len(sys.argv) > 7 else "ip"
     dev = torch.device("cuda:0")
     tdt = torch.float16 if dtype == "fp16" else torch.bfloat16
-    idx = FlatIndex(d, dtype=dtype, device=dev)
+    idx = FlatIndex(d, metric=metric, dtype=dtype, device=dev)
     g = torch.Generator(device=dev)
     g.manual_seed(1234)
     xb = torch.empty((n, idx.dim), dtype=tdt, device=dev)
@@ -63,9 +64,12 @@ def main():
     flops = 2.0 * nq * n * idx.dim
     ach = alg * iters / (scan_ms.value * 1e-3) / 1e9
     S = xq[: min(nq, 4)].float() @ xb[:100000].float().T          # sanity: the top-1 of the first 100k rows
+    if metric == "l2":
+        S = S - 0.5 * (xb[:100000].float() ** 2).sum(1)[None, :]
     sane = bool(((I[: min(nq, 4), 0] >= 100000) | (I[: min(nq, 4), 0] == S.argmax(1))).all())
     print(json.dumps({
-        "workload": f"{n} x {d} {dtype} rows (padded dim {idx.dim}), query batch {nq}, k={k}, exact inner-product top-k, one shard, 1 GPU",
+        "workload": f"{n} x {d} {dtype} rows (padded dim {idx.dim}), query batch {nq}, k={k}, exact {'squared-L2' if metric == 'l2' else 'inner-product'} top-k, one shard, 1 GPU",
+        "kernel": lib().rr_flat_scan_kernel_name(idx.dim, nq).decode(),
         "median_ms": round(med, 4), "p10_ms": round(per[len(per) // 10], 4), "p90_ms": round(per[(9 * len(per)) // 10], 4),
         "queries_per_s": round(nq / med * 1e3, 1), "end_to_end_GBps": round(alg / med / 1e6, 1),
         "end_to_end_frac_of_8TBps": round(alg / med / 1e6 / 8000, 4),
