@@ -1,9 +1,11 @@
 """Device buffers with a REAL guard behind them, for the over-read tests: HIP's virtual-memory API reserves an address range one
 granule longer than the buffer and maps physical memory only under the buffer, so the first byte past it is unmapped by
 construction — whatever the caching allocator's state (PyTorch's `torch.empty` may hand out the middle of a cached segment, which
-made part of round 2's guard runs vacuous).  Mappings are pooled and never unmapped while the process lives: re-mapping recycled
-physical pages at recycled addresses showed stale data in a search's inputs once (a cache holding lines of the previous tenant),
-which is a property of the test harness, not of the code under test.  Test infrastructure only."""
+made part of round 2's guard runs vacuous).  Mappings are pooled and never unmapped while the process lives: a virtual address that
+is unmapped and mapped again onto other physical pages is read STALE by shaders for a while - PyTorch's own kernels included, while
+hipMemcpy of the same range returns the bytes written (root-caused in round 4: tools/remap_probe.py, profiles/r04/remap_probe.json,
+profiles/r03/stale_input_note.md) - which is a property of hipMemUnmap / hipMemMap address re-use on this driver stack, not of the
+code under test.  Test infrastructure only."""
 import ctypes
 
 import torch

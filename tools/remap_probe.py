@@ -7,7 +7,9 @@ Per cycle, exactly what the guard tests did before the pool: reserve + create + 
 queries (hipMemAddressReserve / hipMemCreate / hipMemMap, data copied in with a torch kernel), search, unmap + release + free.
 Recycled virtual addresses and recycled physical pages then meet in new combinations every cycle.  After each fill, BEFORE the
 search, the same bytes are read back three ways and compared with what was written:
-    torch     : view.clone() (a plain vector-load kernel, default cache policy)
+    torch     : view.clone() (a plain vector-load kernel, default cache policy; a small grid: a few CUs)
+    torch_wide: an int64 sum over 256 stride-0 copies of the buffer (a multi-block torch reduction: plain loads from MANY CUs on every
+                XCD, which is what distinguishes the library's persistent 256-workgroup kernels from the clone above)
     memcpy    : hipMemcpy device -> host of the range (blit / SDMA path)
     rr        : the search itself against the oracle (corpus through non-temporal LDS-DMA, queries through global loads and the
                 prep kernel, range / threshold tables through the scalar cache)
@@ -64,8 +66,15 @@ def main():
     events, searches, va_reuse = [], 0, 0
 
     def check(tag, buf, want_bytes, when):
-        got_t = buf.tensor((len(want_bytes),), torch.uint8).clone().cpu().numpy()
+        t8 = buf.tensor((len(want_bytes),), torch.uint8)
+        wide = int(t8.unsqueeze(0).expand(256, -1).sum(dtype=torch.int64))       # read FIRST: the first many-CU access after the fill
+        got_t = t8.clone().cpu().numpy()
         got_m = read_memcpy(buf, len(want_bytes))
+        want_wide = 256 * int(want_bytes.astype(np.int64).sum())
+        if wide != want_wide:
+            events.append({"buffer": tag, "path": "torch_wide", "when": when, "sum": wide, "expected": want_wide,
+                           "narrow_clone_right": bool(np.array_equal(got_t, want_bytes)), "memcpy_right": bool(np.array_equal(got_m, want_bytes))})
+            print(json.dumps(events[-1]), flush=True)
         for path, got in (("torch", got_t), ("memcpy", got_m)):
             if not np.array_equal(got, want_bytes):
                 off = int(np.flatnonzero(got != want_bytes)[0])
