@@ -145,7 +145,7 @@ const char kBuildFlags[] = "unknown (not built by ragroute_amd/_build.py)";
 
 extern "C" {
 
-int rr_version(void) { return 400; }  // 0.4.0: segmented search, in-place merge of the exchange buffer, rr_build_flags
+int rr_version(void) { return 500; }  // 0.5.0: row-split wide-row kernel for L2 / any k / 193+ queries (8 candidate buffers per workgroup on wide rows at every k: larger workspace), tuning variables ignored by product builds, cursor-free plain scans
 const char* rr_build_flags(void) { return kBuildFlags; }
 const char* rr_last_error(void) { return g_err; }
 int rr_device_cus(void) {

@@ -20,11 +20,15 @@
 #   service [ROWS WINDOWS...]   tools/service_bench.py
 #   fuzz SEED COUNT [segments|big]   tools/fuzz_parity.py
 #   probe CYCLES          tools/remap_probe.py (stale-input root-cause probe)
+#   rswiden               the row-split kernel's widened dispatch against round 3's limits (development library _dev, one leg per old limit;
+#                         profiles/r04/rowsplit_widening.json)
+#   config2               config 2: bootstrap sample size A/B (development library) + per-search kernel timeline (tools/trace_gaps.py;
+#                         profiles/r04/config2_floor.json)
 # variables: OUT, SHAPES ("rows dim;rows dim ..."), K, ITERS, BATCH, REPS, ENVS, STEPS
 export TMPDIR=/tmp PYTHONPATH=.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 task=$1; shift
-O=gpurun_out/${OUT:-$task}; mkdir -p $O
+O=gpurun_out/${OUT:-$task}; mkdir -p $O; O_BASE=${OUT:-$task}
 SHAPES=${SHAPES:-"1000000 768;4000000 1024;2000000 2048;2000000 4096;10000000 768 1"}
 REPS=${REPS:-2}; STEPS=${STEPS:-30}
 
@@ -59,7 +63,7 @@ profiles)
   (cd /tmp && rocprofv3 --pmc FETCH_SIZE -d $R/$O/pmc_fetch -o t --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --sustained-seconds 0 > $R/$O/pmc_fetch.log 2>&1) || exit 1
   (cd /tmp && rocprofv3 --pmc WRITE_SIZE -d $R/$O/pmc_write -o t --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --sustained-seconds 0 > $R/$O/pmc_write.log 2>&1) || exit 1
   F=$(find $O/pmc_fetch -name '*counter_collection.csv' | head -1); W=$(find $O/pmc_write -name '*counter_collection.csv' | head -1)
-  python tools/pmc_traffic.py $F $W 15 $O/traffic.json 10000000 768 256 32 fp16 $VER || exit 1
+  python tools/pmc_traffic.py $F $W 9 $O/traffic.json 10000000 768 256 32 fp16 $VER || exit 1
   IFS=';' read -ra SH <<< "$SHAPES"
   for shape in "${SH[@]}"; do
     tag=$(echo $shape | tr ' ' '_')
@@ -124,6 +128,16 @@ service)
   timeout -k 10 700 python tools/service_bench.py "$@" > $O/service.json 2> $O/service.err; grep -v amdgpu.ids $O/service.err | cut -c1-330 ;;
 fuzz)
   timeout -k 10 1000 python tools/fuzz_parity.py "$@" > $O/fuzz_$(echo "$@" | tr ' ' '_').log 2>&1; rc=$?; tail -1 $O/fuzz_$(echo "$@" | tr ' ' '_').log | cut -c1-300; exit $rc ;;
+rswiden)
+  OUT=$O_BASE/rs_k300 SHAPES="2000000 2048" K=300 ITERS=20 ENVS="RR_WIDE_RS_MAXK=128;RR_WIDE_RS_MAXK=1024" bash tools/collect.sh ab _dev
+  OUT=$O_BASE/rs_l2 SHAPES="4000000 1024;2000000 4096" K=10 METRIC=l2 ITERS=20 ENVS="RR_WIDE_RS_L2=0;RR_WIDE_RS_L2=1" bash tools/collect.sh ab _dev
+  for q in 193 200 208; do
+    OUT=$O_BASE/rs_q$q SHAPES="4000000 1024;2000000 2048;2000000 4096" K=10 BATCH=$q ITERS=20 ENVS="RR_WIDE_RS_MINQ=209;RR_WIDE_RS_MINQ=193" bash tools/collect.sh ab _dev
+  done ;;
+config2)
+  OUT=$O_BASE/c2_sample SHAPES="1000000 768" K=32 ITERS=50 REPS=3 ENVS="RR_SAMPLE_ROWS=8192;RR_SAMPLE_ROWS=4096;RR_SAMPLE_ROWS=2048" bash tools/collect.sh ab _dev
+  (cd /tmp && rocprofv3 --kernel-trace -d $R/$O/trace -o t --output-format csv -- python3 $R/tools/shape_bench.py 1000000 768 256 32 fp16 30 > $R/$O/shape.json 2> $R/$O/trace.err)
+  python tools/trace_gaps.py $(find $O/trace -name '*kernel_trace.csv' | head -1) 9 20 | tee $O/gaps.json ;;
 probe)
   timeout -k 10 900 python tools/remap_probe.py "$@" > $O/remap_probe.log 2>&1; rc=$?; tail -3 $O/remap_probe.log | cut -c1-1500; exit $rc ;;
 *) echo "unknown task $task"; exit 2 ;;
