@@ -1,11 +1,12 @@
-"""Diagnostic (RR_SCAN_TIMELINE=1): per-workgroup start/end times of the LAST chunk scan of a search (s_memrealtime, 100 MHz)."""
+"""Diagnostic (RR_SCAN_TIMELINE=1, DEVELOPMENT library: RR_LIB_OVERRIDE=ragroute_amd/libragroute_hip_dev.so): per-workgroup start /
+first-tile-ready / end times of the LAST chunk scan of a search (s_memrealtime, 100 MHz).    python tools/timeline.py [rows]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["RR_SCAN_TIMELINE"] = "1"
 import torch
 from ragroute_amd.flat_index import FlatIndex
 
-n, d, nq, k = 10_000_000, 768, 256, 32
+n, d, nq, k = (int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000), 768, 256, 32
 dev = torch.device("cuda:0")
 idx = FlatIndex(d, device=dev)
 g = torch.Generator(device=dev); g.manual_seed(1234)
@@ -20,7 +21,14 @@ for _ in range(4):
 torch.cuda.synchronize()
 ws = idx._ws[k]
 grid = 256
-off = 1024 + 1024 + 1024 + 256 * 1024 * 8 + 256 * grid * 4 * 4 + grid * 8 * 64 * 8
+
+
+def up(v):
+    return (v + 255) // 256 * 256
+
+
+# offset of the dense-sample buffer (idle during chunk scans: the timeline lands there) in capi.hip::carve's layout, dim <= 768, k = 32
+off = sum(up(b) for b in (32 * 256 * 4, 32 * 4, 32 * 4, 32 * 4, 32 * 8, 256 * 4, 12 * 32 * 16, 256 * 4, 256 * 1024 * 8, 256 * grid * 4 * 4, grid * 8 * 64 * 8))
 raw = ws[off: off + (3 * grid + 65 * grid) * 8].view(torch.int64).cpu().double()
 t = raw[: 3 * grid].reshape(3, grid)
 first_ready = raw[3 * grid + 64 * grid:] / 100.0
