@@ -220,3 +220,65 @@ def _slice_worker(rank, world, port, out_dir, planned):
 def test_one_source_in_three_slices_over_two_ranks(tmp_path, planned):
     mp.spawn(_slice_worker, args=(2, _free_port(), str(tmp_path), planned), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+# ---- world 8 over gloo: the planner's own FeB4RAG-shaped plan, every rank's units, uneven slots -------------------------------
+def _feb4rag_small():
+    """FeB4RAG's thirteen sources at 1/1000 of their row counts (encoders and order of config.py:32-57), widths scaled 1/16."""
+    fed = []
+    for s in P.federation("feb4rag"):
+        fed.append(P.Source(s.sid, max(3, s.rows // 1000), s.dim // 16, s.encoder, name=s.name))
+    return fed
+
+
+def _eight_rank_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        from oracle import oracle as O
+        from ragroute_amd import pipeline as PL
+        from ragroute_amd.sharded import unpack_gathered
+        from tests.util import int_data
+        O.set_threads(1)
+
+        def merge_gathered_cpu(out, B, k_in, slots, k, descending=True):
+            Dg, Ig = unpack_gathered(out, B, k_in, slots)
+            return tuple(torch.from_numpy(a) for a in O.merge_topk(Dg.numpy(), Ig.numpy(), k, descending))
+        PL.merge_gathered = merge_gathered_cpu
+        fed = _feb4rag_small()
+        pl = P.plan(fed, world, cost=P.CostModel(fixed_ms=1e-6, segment_ms=0.0), min_slice_rows=256)
+        assert sum(len(pl.slices_of(s.sid)) - 1 for s in fed) >= 4, "the plan should cut the large sources"
+        rng = np.random.default_rng(77)                      # the same stream on every rank
+        corpora = {s.sid: int_data(rng, s.rows, s.dim) for s in fed}
+        nq, k = 11, 10
+        emb = {e: int_data(rng, nq, next(s.dim for s in fed if s.encoder == e)) for e in sorted({s.encoder for s in fed})}
+        mask = rng.integers(0, 2, size=(nq, len(fed))).astype(bool)
+        mask[0] = False
+        mask[1] = True
+        units = []
+        for u in pl.ranks[rank]:
+            pieces = [(corpora[s.sid][s.row_begin: s.row_begin + s.n_rows], s.id_offset, s.sid) for s in u.slices]
+            units.append(("segments" if len(pieces) > 1 else "shard", _OracleSlice(pieces, len(pieces) > 1), [s.sid for s in u.slices],
+                          None if len(pieces) > 1 else pieces[0][1]))
+        pipe = PL.RetrievalPipeline([], [], router=_FixedRouter(torch.from_numpy(mask)), slots=pl.slots)
+        pipe.units = units
+        xq = {s.sid: torch.from_numpy(emb[s.encoder]) for s in fed}
+        D, I = pipe.search(xq, k, xq_models=torch.zeros(nq, 1, 1))
+        D2, I2 = pipe.search(xq, k, xq_models=torch.zeros(nq, 1, 1))          # the reused packed / gathered buffers
+        want_D, want_I = expected_chain(O, fed, corpora, emb, mask, nq, k)
+        assert I.numpy().tolist() == want_I and D.numpy().tolist() == want_D
+        assert torch.equal(I, I2) and torch.equal(D, D2)
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write(f"{len(units)} {pl.slots}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_feb4rag_shaped_plan(tmp_path):
+    """World 8 on the CPU (gloo): the planner's plan of a FeB4RAG-shaped federation - 13 sources, 8 encoders, three widths, several cuts,
+    ranks with different unit counts (unused exchange slots stay padding) - every rank searching its own units, ONE packed exchange,
+    merge: identical to the reference's flow on the whole sources for every query, on every rank."""
+    mp.spawn(_eight_rank_worker, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
+    got = [open(tmp_path / f"ok{r}").read().split() for r in range(8)]
+    assert len({g[1] for g in got}) == 1 and max(int(g[0]) for g in got) == int(got[0][1])
+    assert len({g[0] for g in got}) > 1, "the ranks should hold different unit counts"
