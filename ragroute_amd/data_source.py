@@ -244,13 +244,25 @@ class DataSource:
                 self.mmlu_texts = f.read().splitlines()
         self.set_index(xb, metadatas)
 
+    def pick_device(self):
+        """The GPU this data-source PROCESS keeps its corpus on.  The reference starts one process per source (ragroute.py:10-16)
+        and knows no devices; on a multi-GPU node the drop-in spreads those processes over the visible GPUs: `RAGROUTE_DEVICE`
+        (an index or "cuda:i") if set, else `client_id mod device_count` - SURVEY 8e's source s -> GPU s mod G for the module
+        surface (the device-side pipeline balances by row slices instead: placement.py).  None = the current device."""
+        import torch
+        env = os.environ.get("RAGROUTE_DEVICE")
+        if env:
+            return torch.device(env if ":" in env else f"cuda:{int(env)}")
+        n = torch.cuda.device_count()
+        return torch.device(f"cuda:{self.client_id % n}") if n > 1 else None
+
     def set_index(self, xb, metadatas, titles=None, texts=None):
         """Install a corpus directly: xb float32 [n,d] (numpy / memmap) or an existing FlatIndex."""
         if isinstance(xb, FlatIndex):
             index = xb
         else:
             metric = getattr(self, "index_metric", "ip")
-            index = FlatIndex(xb.shape[1], metric=metric, dtype=self.dtype)
+            index = FlatIndex(xb.shape[1], metric=metric, dtype=self.dtype, device=self.pick_device())
             index.reserve(xb.shape[0])
             index.add(xb)
         self.faiss_indexes = index, metadatas

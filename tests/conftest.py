@@ -20,3 +20,15 @@ def gpu():
     from ragroute_amd import _lib
     _lib.lib()  # fail loudly if the HIP extension is missing
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _restore_gc_settings():
+    """DataSource.start() tunes the garbage collector of its (service) process (DataSource.tune_runtime: gc.freeze + thresholds);
+    tests that run a service loop in the pytest process must not leave that behind for the tests after them."""
+    import gc
+    before = gc.get_threshold()
+    yield
+    if gc.get_threshold() != before:
+        gc.set_threshold(*before)
+        gc.unfreeze()

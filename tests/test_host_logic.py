@@ -84,6 +84,22 @@ def test_data_source_paths_follow_reference(monkeypatch):
         DataSource(0, "nope", "x")
 
 
+def test_data_source_processes_spread_over_the_visible_gpus(monkeypatch):
+    """One process per source (ragroute.py:10-16): client_id mod device_count, RAGROUTE_DEVICE overrides, one GPU = current device."""
+    import torch
+    from ragroute_amd.data_source import DataSource
+    monkeypatch.delenv("RAGROUTE_DEVICE", raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    assert [str(DataSource(c, "feb4rag", "msmarco").pick_device()) for c in (0, 5, 8, 12)] == ["cuda:0", "cuda:5", "cuda:0", "cuda:4"]
+    monkeypatch.setenv("RAGROUTE_DEVICE", "3")
+    assert str(DataSource(0, "medrag", "pubmed").pick_device()) == "cuda:3"
+    monkeypatch.setenv("RAGROUTE_DEVICE", "cuda:6")
+    assert str(DataSource(1, "medrag", "pubmed").pick_device()) == "cuda:6"
+    monkeypatch.delenv("RAGROUTE_DEVICE")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert DataSource(2, "medrag", "pubmed").pick_device() is None
+
+
 def test_router_strategies_without_weights():
     from ragroute_amd import config as C
     from ragroute_amd.router import Router
