@@ -10,7 +10,7 @@ DIMS = [8, 64, 100, 128, 256, 384, 500, 512, 640, 768, 769, 896, 1000, 1024, 115
         2816, 3072, 3200, 4096, 5120, 8192]
 QUERIES = [1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 300]
 ROWS = [1, 31, 32, 33, 255, 256, 257, 1000, 8191, 8192, 8193, 8224, 10_000, 16_384, 20_011, 33_000, 50_000]
-KS = [1, 5, 10, 32, 33, 100, 128, 300]
+KS = [1, 5, 10, 32, 33, 100, 128, 129, 300, 600, 1024]   # (129 ... 1024 on wide rows: the row-split kernel's any-k path, round 4)
 
 
 ROWS_BIG = [70_000, 131_072, 300_000, 524_288, 1_000_000, 2_000_000]   # several chunks of the geometric schedule
