@@ -106,24 +106,43 @@ class MedragMetadata:
 
     @classmethod
     def from_jsonl(cls, path):
-        """Returns a MedragMetadata, or the plain list of dicts if a line carries anything but exactly {"index", "source"}."""
-        index, code, names, lookup, plain = [], [], [], {}, None
+        """Returns a MedragMetadata, or the plain list of dicts if a line carries anything but exactly {"index", "source"}.
+        The file is streamed (pubmed's has 23.9 M lines): the lines are those of `file.read().strip().split("\\n")`
+        (data_source.py:73) - blank lines at the ends are dropped, a blank line in the middle fails in json.loads as it does there."""
+        from array import array
+        index, code, names, lookup, plain = array("q"), array("i"), [], {}, None
+        pending_blank = 0
+        started = False
         with open(path, "r") as f:
-            lines = f.read().strip().split("\n")
-        for n, line in enumerate(lines):
-            m = json.loads(line)
-            if plain is None and (len(m) != 2 or not isinstance(m.get("index"), int) or isinstance(m.get("index"), bool) or not isinstance(m.get("source"), str)):
-                plain = [{"index": int(i), "source": names[c]} for i, c in zip(index, code)]
-            if plain is not None:
-                plain.append(m)
-                continue
-            c = lookup.get(m["source"])
-            if c is None:
-                c = lookup[m["source"]] = len(names)
-                names.append(m["source"])
-            index.append(m["index"])
-            code.append(c)
-        return plain if plain is not None else cls(index, code, names)
+            for raw in f:
+                line = raw.rstrip("\n")
+                if not line.strip():
+                    if started:
+                        pending_blank += 1          # only an error if a non-blank line follows
+                    continue
+                if not started:
+                    line = line.lstrip()            # .strip() of the whole text removes leading whitespace of the first line ...
+                    started = True
+                if pending_blank:
+                    json.loads("")                  # the reference would be parsing an empty line here: same JSONDecodeError
+                m = json.loads(line)
+                if plain is None and (not isinstance(m, dict) or len(m) != 2 or type(m.get("index")) is not int or not isinstance(m.get("source"), str)):
+                    plain = [{"index": int(i), "source": names[c]} for i, c in zip(index, code)]
+                if plain is not None:
+                    plain.append(m)
+                    continue
+                c = lookup.get(m["source"])
+                if c is None:
+                    c = lookup[m["source"]] = len(names)
+                    names.append(m["source"])
+                index.append(m["index"])
+                code.append(c)
+        if not started:
+            json.loads("")                          # an empty file: `"".split("\\n")` is [""], which the reference fails to parse
+        if plain is not None:
+            return plain
+        return cls(np.frombuffer(index, np.int64) if len(index) else np.zeros(0, np.int64),
+                   np.frombuffer(code, np.int32) if len(code) else np.zeros(0, np.int32), names)
 
     def __len__(self):
         return len(self.index)
