@@ -493,6 +493,9 @@ class DataSource:
         """Stop serving and close the sockets (data_source.py:217-222)."""
         self.running = False
         task, self._serve_task = getattr(self, "_serve_task", None), None
+        batcher = self._batcher
+        if batcher is not None:
+            batcher.shutdown_threads()       # the search / reply threads of the two-stage batcher end with the service
         for name in ("receiver", "sender"):
             sock = getattr(self, name, None)
             if sock is not None:

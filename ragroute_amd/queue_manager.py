@@ -208,6 +208,14 @@ class QueryBatcher:
             self._inflight.add(prev)
             prev.add_done_callback(self._inflight.discard)
 
+    def shutdown_threads(self):
+        """End the search / reply worker threads (two-stage form); safe from any thread, idempotent.  Requests still in flight are
+        failed by the cancellation of the service loop that owns them."""
+        pools, self._pools = self._pools, None
+        if pools is not None:
+            for p in pools:
+                p.shutdown(wait=False)
+
     async def close(self):
         if self._worker is not None:
             self._worker.cancel()
@@ -218,7 +226,4 @@ class QueryBatcher:
             self._worker = None
         for t in list(self._inflight):
             t.cancel()
-        if self._pools is not None:
-            for p in self._pools:
-                p.shutdown(wait=False)
-            self._pools = None
+        self.shutdown_threads()
