@@ -282,3 +282,42 @@ def test_eight_ranks_feb4rag_shaped_plan(tmp_path):
     got = [open(tmp_path / f"ok{r}").read().split() for r in range(8)]
     assert len({g[1] for g in got}) == 1 and max(int(g[0]) for g in got) == int(got[0][1])
     assert len({g[0] for g in got}) > 1, "the ranks should hold different unit counts"
+
+
+# ---- property test: random federations -------------------------------------------------------------------------------------------
+def test_planner_invariants_on_random_federations():
+    from hypothesis import given, settings, strategies as st
+    dims = st.sampled_from([64, 100, 384, 768, 1024, 1536, 2048, 4096])
+    source = st.tuples(st.integers(0, 40_000_000), dims, st.integers(0, 5), st.sampled_from(["ip", "ip", "ip", "l2"]))
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(source, min_size=1, max_size=18), st.integers(1, 16))
+    def check(specs, G):
+        fed = [P.Source(i, rows, dim, f"enc{enc}-{dim}", metric) for i, (rows, dim, enc, metric) in enumerate(specs)]
+        pl = P.plan(fed, G)
+        assert len(pl.ranks) == G
+        _covered(pl)
+        cuts = 0
+        for sid, src in pl.sources.items():
+            sl = pl.slices_of(sid)
+            cuts += len(sl) - 1
+            if len(sl) > 1:
+                assert all(s.n_rows >= P.MIN_SLICE_ROWS for s in sl)
+        assert cuts <= G - 1
+        for units in pl.ranks:
+            keys = [u.group for u in units if u.group[2] != "l2"]
+            assert len(keys) == len(set(keys))                      # the pieces of one group on a rank are ONE unit
+            for u in units:
+                assert len({(pl.sources[s.sid].encoder, P.padded_dim(pl.sources[s.sid].dim), pl.sources[s.sid].metric) for s in u.slices}) == 1
+                assert [s.id_offset for s in u.slices] == sorted(s.id_offset for s in u.slices)
+                if u.group[2] == "l2":
+                    assert len(u.slices) == 1
+        # never worse than everything on one rank, and within the model's granularity of the ideal share
+        cost = P.CostModel()
+        one = P.plan(fed, 1).predicted_ms[0]
+        assert max(pl.predicted_ms) <= one + 1e-6
+        biggest_uncuttable = max((cost.row_ms(s) * min(s.rows, 2 * P.MIN_SLICE_ROWS) for s in fed), default=0.0)
+        assert max(pl.predicted_ms) <= one / G + biggest_uncuttable + cost.fixed_ms * (len(fed) + 1) + 1e-6
+        assert P.plan(fed, G).describe() == pl.describe()           # deterministic
+
+    check()
