@@ -32,7 +32,9 @@ enum { RR_MAX_K = 1024, RR_QUERY_BLOCK = 256 };
 int rr_version(void);
 /* The compiler flags this library was built with (ragroute_amd/_build.py).  A product build carries no -D switch: the
  * development kernels (RR_DEV_VARIANTS) and the timing-only ablations that exist inside such builds are then not compiled
- * in, and a test can tell the library under test from an A/B build. */
+ * in, and a test can tell the library under test from an A/B build.  A product build also reads NO environment variable:
+ * the RR_* tuning variables (kernel selection, chunk schedule, sample size, timelines) are honoured by -DRR_DEV_VARIANTS
+ * builds only. */
 const char* rr_build_flags(void);
 /* Message of the last failure on the calling thread ("" if none). */
 const char* rr_last_error(void);
@@ -100,7 +102,9 @@ int rr_flat_search(const void* d_xb, int dtype, int64_t n_rows, int dim, const v
  *   d_xb      ONE device matrix [n_rows_total][dim]; segment s = rows [row_begin, row_begin + n_rows) of it.  Segments are
  *             ascending, do not overlap and begin at multiples of RR_SEGMENT_ALIGN rows; rows between segments (alignment
  *             gaps) may hold anything finite or not — they are scanned but never returned.
- *   segs      HOST array of n_segs (<= RR_MAX_SEGMENTS) descriptors
+ *   segs      HOST array of n_segs (<= RR_MAX_SEGMENTS) descriptors.  A segment is a whole source, or a ROW SLICE of one (a source
+ *             cut over several GPUs, ragroute_amd/placement.py: several segments may then share a mask_col): its id_offset is
+ *             (source << 40) + the slice's first row, so the ids it returns are the whole source's ids
  *   d_I       result ids: id_offset + (row - row_begin) of the row's segment, or -1.  Ties are broken by (segment order,
  *             row), i.e. by ascending id when the id_offsets ascend with the segments.
  *   d_route_mask  optional device u8 [nq][mask_stride]: segment s serves query q iff mask_col < 0 or
