@@ -72,3 +72,52 @@ def test_full_size_planted_neighbours(gpu):
     # sub-batch property: the first 7 queries alone give the same rows
     D3, I3 = idx.search_prepared(xq[:7].contiguous(), k)
     assert torch.equal(I3, I[:7]) and torch.equal(D3, D[:7])
+
+
+@pytest.mark.parametrize("dataset", ["feb4rag", "medrag"])
+def test_sliced_placement_is_placement_independent_at_scale(gpu, dataset):
+    """BASELINE configs 4 / 3 at 1/8 of the federations' real row counts (same widths, encoders and source order; synthetic rows
+    that are a pure function of (source, row), tools/workloads.py): the 8-GPU placement of placement.plan, every rank's units built
+    and searched in turn on this device and merged, against the one-GPU search of the same federation - the row slices, the
+    per-rank segmented units and the 40 exchange candidates per query must not change one id or score.  (The oracle cannot scan
+    millions of rows in seconds: this is the size-independent property; small cases against the oracle: test_placement_gpu.py.)"""
+    from ragroute_amd import config as C
+    from ragroute_amd import placement as P
+    from ragroute_amd.pipeline import RetrievalPipeline
+    from ragroute_amd.rerank import merge_topk
+    from tools import workloads as W
+    fed = P.federation(dataset, rows={name: max(64, n // 8) for name, n in P.ROWS[dataset].items()})
+    k, B = C.K[dataset], 256
+    emb = W.query_embeddings(fed, B, gpu)
+    xq = W.queries_by_source(fed, emb)
+    xq_models = W.pack_router_input(dataset, fed, emb, gpu)
+    g = torch.Generator(device=gpu)
+    g.manual_seed(5)
+    mask = torch.rand((B, len(fed)), generator=g, device=gpu) < 0.7        # a fixed random route mask, some queries routed nowhere
+    mask[:4] = False
+
+    class Fixed:
+        def run(self, _):
+            return None, mask
+
+    def run(plan):
+        out = []
+        for r in range(len(plan.ranks)):
+            pipe = RetrievalPipeline.from_placement(plan, r, fill_half=W.fill_half, router=Fixed(), device=gpu)
+            D, I = pipe.search(xq, k, xq_models=xq_models)
+            out.append((D.clone(), I.clone()))
+            del pipe
+            torch.cuda.empty_cache()
+        return out
+
+    D1, I1 = run(P.plan(fed, 1))[0]
+    plan8 = P.plan(fed, 8, cost=P.CostModel(fixed_ms=0.01, segment_ms=0.00125))   # fixed costs scaled with the rows: the full-size plan's cuts
+    assert sum(len(plan8.slices_of(s.sid)) - 1 for s in fed) >= 4
+    parts = run(plan8)
+    Dm, Im = merge_topk(torch.cat([d for d, _ in parts], 1), torch.cat([i for _, i in parts], 1), k, True)
+    assert torch.equal(Im, I1) and torch.equal(Dm, D1)
+    assert bool((I1[:4] == -1).all()) and bool((I1[4:, 0] >= 0).any())
+    # ... and the whole-source layout (source s -> GPU s mod 8) gives the same answer
+    whole = run(P.whole_source_plan(fed, 8))
+    Dw, Iw = merge_topk(torch.cat([d for d, _ in whole], 1), torch.cat([i for _, i in whole], 1), k, True)
+    assert torch.equal(Iw, I1) and torch.equal(Dw, D1)
