@@ -321,3 +321,21 @@ def test_planner_invariants_on_random_federations():
         assert P.plan(fed, G).describe() == pl.describe()           # deterministic
 
     check()
+
+
+def test_synthetic_federation_rows_do_not_depend_on_the_slicing():
+    """tools/workloads.fill_half: row r of source s is a pure function of (s, r) - whatever slices hold it (what makes
+    bench.py --workload's result checksums comparable across placements and GPU counts)."""
+    from tools import workloads as W
+    src = P.Source(3, 2 * W.BLOCK + 1234, 32, "enc")
+    whole = torch.zeros((src.rows, 128), dtype=torch.float16)
+    W.fill_half(src, P.RowSlice(3, 0, src.rows), whole)
+    cuts = [0, 256 * 7, W.BLOCK - 256, W.BLOCK + 512, src.rows]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        part = torch.zeros((b - a, 128), dtype=torch.float16)
+        W.fill_half(src, P.RowSlice(3, a, b - a), part)
+        assert torch.equal(part, whole[a:b])
+    assert float(whole[:, 32:].abs().max()) == 0.0 and float(whole[:, :32].float().norm(dim=1).sub(1).abs().max()) < 2e-3
+    other = torch.zeros((16, 128), dtype=torch.float16)
+    W.fill_half(P.Source(4, 16, 32, "enc"), P.RowSlice(4, 0, 16), other)
+    assert not torch.equal(other, whole[:16])
