@@ -12,7 +12,6 @@ import numpy as np
 import torch
 
 from ragroute_amd import config as C
-from ragroute_amd import placement as P
 
 BLOCK = 1 << 18
 
