@@ -148,3 +148,43 @@ def test_pipelined_batcher_failures_stay_in_their_window():
         QueryBatcher(search=lambda i: i)
     with pytest.raises(ValueError):
         QueryBatcher()
+
+
+def test_pipelined_batcher_survives_cancelled_and_timed_out_requests():
+    """Clients that give up (asyncio.wait_for timeouts, cancelled tasks) must not wedge the batcher, leak `_open` counts (the window
+    cap is derived from them) or lose other requests' results."""
+    import random
+
+    def search(items):
+        time.sleep(0.002)
+        return list(items)
+
+    def finish(handle):
+        time.sleep(0.001)
+        return [x + 1 for x in handle]
+
+    async def go():
+        b = QueryBatcher(search=search, finish=finish, max_batch=64, max_wait_ms=0.5)
+        rnd = random.Random(3)
+        ok = lost = 0
+
+        async def client(i):
+            nonlocal ok, lost
+            try:
+                r = await asyncio.wait_for(b.submit(i), timeout=rnd.choice([0.0005, 0.002, 0.01, 1.0]))
+                assert r == i + 1
+                ok += 1
+            except asyncio.TimeoutError:
+                lost += 1
+
+        for wave in range(10):
+            tasks = [asyncio.ensure_future(client(wave * 300 + i)) for i in range(300)]
+            for t in rnd.sample(tasks, 20):
+                t.cancel()
+            await asyncio.gather(*tasks, return_exceptions=True)
+        assert b._open == 0 and not b._pending
+        assert await asyncio.wait_for(b.submit(41), timeout=2.0) == 42          # still serving
+        await b.close()
+        return ok, lost
+    ok, lost = asyncio.run(go())
+    assert ok > 500 and lost > 0
