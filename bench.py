@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--workload", default="headline", choices=["headline", "feb4rag", "medrag"],
                     help="headline: equal synthetic 10M x 768 shards (BASELINE metric); feb4rag / medrag: the federation at its real shapes, sliced over the GPUs")
     ap.add_argument("--placement", default="sliced", choices=["sliced", "whole"], help="--workload feb4rag|medrag: balanced row slices, or source s -> GPU s mod G")
+    ap.add_argument("--workload-scale", type=int, default=1, help="--workload: divide every source's row count by this (tests / rehearsals; 1 = the real shapes)")
     ap.add_argument("--total-shards", type=int, default=8, help="--scaling strong: shards of the fixed federation")
     ap.add_argument("--rows", type=int, default=10_000_000, help="corpus rows per shard")
     ap.add_argument("--dim", type=int, default=768)
@@ -157,7 +158,8 @@ def main():
         from ragroute_amd import placement as PL
         from tools import workloads as W
         k = args.k if args.k is not None else RC.K[args.workload]
-        fed = PL.federation(args.workload)
+        fed = PL.federation(args.workload, rows=None if args.workload_scale == 1 else
+                            {name: max(64, rows // args.workload_scale) for name, rows in PL.ROWS[args.workload].items()})
         plan = PL.plan(fed, world) if args.placement == "sliced" else PL.whole_source_plan(fed, world)
         pipe = RetrievalPipeline.from_placement(plan, rank, fill_half=W.fill_half, device=dev)
         cen = W.local_centroids(args.workload, fed, pipe, dev)
@@ -305,10 +307,10 @@ def main():
         if fed_mode:
             total_rows = sum(s_.rows for s_ in fed)
             total_gb = sum(s_.rows * s_.row_bytes for s_ in fed) / 1e9
-            config = {"workload": f"{args.workload}: {C} sources at their real row counts and encoder widths ({total_rows} rows, {total_gb:.1f} GB fp16), "
+            config = {"workload": f"{args.workload}: {C} sources at {'their real row counts' if args.workload_scale == 1 else f'1/{args.workload_scale} of their real row counts'} and encoder widths ({total_rows} rows, {total_gb:.1f} GB fp16), "
                                   f"{'balanced row slices (placement.plan)' if args.placement == 'sliced' else 'source s -> GPU s mod G'} over {world} GPU(s), "
                                   f"query batch {B}, k={k}, router MLP + per-unit exact top-k + ONE all_gather + merge",
-                      "dataset": args.workload, "placement": args.placement, "rows_total": total_rows, "corpus_GB": round(total_gb, 2), "batch": B, "k": k,
+                      "dataset": args.workload, "row_scale": f"1/{args.workload_scale}", "placement": args.placement, "rows_total": total_rows, "corpus_GB": round(total_gb, 2), "batch": B, "k": k,
                       "sources": C, "units_per_rank": [len(u) for u in plan.ranks], "exchange_slots": pipe.slots,
                       "predicted_ms_per_rank": [round(t, 3) for t in plan.predicted_ms],
                       "parallelism": f"{C} sources in {sum(len(u.slices) for us in plan.ranks for u in us)} row slices over {world} gpu(s)",

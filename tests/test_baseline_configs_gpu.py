@@ -119,3 +119,32 @@ def test_config5_80m_bf16_k100(gpu):
     assert torch.equal(I3, I[:5]) and torch.equal(D3, D[:5])
     del idx, xb
     torch.cuda.empty_cache()
+
+
+def _bench_line(args, env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=dict(os.environ, **(env or {})), capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, res.stdout[-1000:]
+    return json.loads(lines[0])
+
+
+def test_bench_workload_entry_point_is_placement_independent(gpu):
+    """bench.py --workload feb4rag at 1/32 of the real row counts: one rank, two ranks on this device (gloo exchange) with the sliced
+    and with the whole-source placement - three processes trees, the SAME result checksum, and every N > 1 line carries each rank's
+    scan and local times."""
+    common = ["--workload", "feb4rag", "--workload-scale", "32", "--steps", "3", "--warmup", "1", "--sustained-seconds", "0"]
+    one = _bench_line(common)
+    two = _bench_line(common + ["--gpus", "2"], {"RR_BENCH_BACKEND": "gloo", "RR_BENCH_ONE_DEVICE": "1"})
+    whole = _bench_line(common + ["--gpus", "2", "--placement", "whole"], {"RR_BENCH_BACKEND": "gloo", "RR_BENCH_ONE_DEVICE": "1"})
+    assert one["result_checksum"] == two["result_checksum"] == whole["result_checksum"]
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["row_scale"] == "1/32"
+    for line in (two, whole):
+        assert len(line["per_rank_scan_ms"]["ranks"]) == 2 and len(line["per_rank_local_ms"]["ranks"]) == 2
+        assert min(line["per_rank_local_ms"]["ranks"]) > 0 and line["rccl_ranks"] == 2
+    assert sum(two["config"]["units_per_rank"]) >= 8 and two["roofline"]["frac"] > 0
